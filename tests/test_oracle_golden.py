@@ -1,0 +1,171 @@
+"""The CPU oracle (oracle/*.py) against the golden vectors produced by the reference's own
+code (tests/golden/make_golden.py).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_npz, sub
+from oracle import collate_ref, model_ref
+
+INT_KEYS = ['x', 'x_pieces', 'x_pos', 'atom_mask', 'pieces', 'edge_index', 'edge_attr', 'edge_select',
+            'golden_edge', 'in_piece_edge_idx']
+
+
+def collate_cases():
+    with open(os.path.join(GOLDEN, 'collate_cases.json')) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize('name', ['single_atom', 'one_piece_only', 'no_bond_only', 'mixed_small',
+                                  'zinc_ragged', 'qm9_ragged', 'max_size_38'])
+def test_collate_bit_exact(name, tokenizer):
+    step1 = collate_cases()[name]
+    gold = sub(load_npz('collate_cases.npz'), name)
+    batch, used = collate_ref.collate(step1, gold['uniforms'], piece_pad=tokenizer.pad_idx())
+    assert used == len(gold['uniforms'])
+    for k in INT_KEYS:
+        want = gold[k]
+        got = batch[k]
+        if k == 'edge_index' and want.shape[1] == 0:
+            assert got.shape == (2, 0)
+            continue
+        assert got.shape == want.shape, k
+        assert got.dtype == want.dtype, k
+        assert np.array_equal(got, want), k
+    assert np.array_equal(batch['props'], gold['props'].astype(np.float32).reshape(len(step1), -1))
+
+
+def to_torch_batch(npb):
+    return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in npb.items()}
+
+
+def small_model(tokenizer, gold):
+    cfg = model_ref.default_config(tokenizer, latent_dim=8, predictor_hidden_dim=16, node_hidden_dim=36,
+                                   graph_embedding_dim=40, atom_embedding_dim=6, piece_embedding_dim=12,
+                                   pos_embedding_dim=6, piece_hidden_dim=20)
+    model = model_ref.PSVAEModel(cfg, tokenizer)
+    state = {k: torch.from_numpy(v) for k, v in sub(gold, 'state').items()}
+    missing = model.load_state_dict(state, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return model, cfg
+
+
+def test_model_small_forward_backward_step(tokenizer):
+    gold = load_npz('model_small.npz')
+    model, cfg = small_model(tokenizer, gold)
+    batch = to_torch_batch(sub(gold, 'batch'))
+    eps = torch.from_numpy(gold['eps'])
+
+    with torch.no_grad():
+        x = model.decoder.embed_atom(batch['x'], batch['x_pieces'], batch['x_pos'])
+        assert torch.equal(x, torch.from_numpy(gold['act/embed_atom']))
+        B, N, D = x.shape
+        last, all_x = model.encoder.embed_node(x.view(-1, D), batch['edge_index'], batch['edge_attr'])
+        np.testing.assert_allclose(last.numpy(), gold['act/enc_last'], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(all_x.numpy(), gold['act/enc_all_x'], rtol=1e-6, atol=1e-6)
+        gids = torch.repeat_interleave(torch.arange(B), N)
+        genc = model.encoder.embed_graph(all_x, gids, batch['atom_mask'].flatten())
+        np.testing.assert_allclose(genc.numpy(), gold['act/graph_embedding'], rtol=1e-6, atol=1e-6)
+        z, kl = model.decoder.rsample(genc, eps)
+        np.testing.assert_allclose(z.numpy(), gold['act/z'], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(kl.numpy(), gold['act/kl'], rtol=1e-6)
+
+    pred_loss, (losses, accus) = model(batch, eps, return_accu=True)
+    rec, piece, edge, kl = losses
+    loss = model.weighted_loss(pred_loss, rec, kl)
+    for name, val in [('total', loss), ('pred', pred_loss), ('rec', rec), ('piece', piece), ('edge', edge), ('kl', kl)]:
+        np.testing.assert_allclose(val.item(), gold[f'loss/{name}'], rtol=1e-6, err_msg=name)
+    assert accus[0] == pytest.approx(float(gold['accu/piece']))
+    assert accus[1] == pytest.approx(float(gold['accu/edge']))
+    loss.backward()
+    no_grad = set(gold['no_grad_params'].tolist())
+    for k, p in model.named_parameters():
+        if k in no_grad:
+            assert p.grad is None
+            continue
+        np.testing.assert_allclose(p.grad.numpy(), gold[f'grad/{k}'], rtol=1e-4, atol=1e-7, err_msg=k)
+    opt = torch.optim.Adam(model.parameters(), lr=cfg['lr'])
+    total = torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
+    np.testing.assert_allclose(total.item(), gold['grad_total_norm'], rtol=1e-5)
+    opt.step()
+    for k, v in model.state_dict().items():
+        np.testing.assert_allclose(v.numpy(), gold[f'after_step/{k}'], rtol=1e-5, atol=1e-6, err_msg=k)
+
+
+def test_model_default_width_from_seed(tokenizer):
+    """Default widths (H=300, G=400, L=56): weights are re-created from the seed in the same
+    construction order as the reference, outputs compared with the stored ones."""
+    gold = load_npz('model_default.npz')
+    cfg = model_ref.default_config(tokenizer)
+    torch.manual_seed(int(gold['seed']))
+    model = model_ref.PSVAEModel(cfg, tokenizer)
+    batch = to_torch_batch(sub(gold, 'batch'))
+    eps = torch.from_numpy(gold['eps'])
+    pred_loss, (rec, piece, edge, kl) = model(batch, eps)
+    loss = model.weighted_loss(pred_loss, rec, kl)
+    for name, val in [('total', loss), ('pred', pred_loss), ('rec', rec), ('piece', piece), ('edge', edge), ('kl', kl)]:
+        np.testing.assert_allclose(val.item(), gold[f'loss/{name}'], rtol=2e-6, err_msg=name)
+    loss.backward()
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            assert k in set(gold['no_grad_params'].tolist())
+            continue
+        np.testing.assert_allclose(p.grad.norm().item(), gold[f'gradnorm/{k}'], rtol=1e-4, err_msg=k)
+    n_params = sum(p.numel() for p in model.parameters())
+    assert n_params == 1891727      # encoder 722 800 + decoder 1 116 925 + predictor 52 002
+
+
+def test_cal_beta_table(tokenizer):
+    gold = load_npz('beta_table.npz')
+    for name in ('train_sh', 'warmup'):
+        warm, anneal, max_beta, step_beta, beta0 = gold[name + '/config']
+        cfg = {'kl_warmup': int(warm), 'kl_anneal_iter': int(anneal), 'max_beta': float(max_beta),
+               'step_beta': float(step_beta), 'beta': float(beta0)}
+        got = np.asarray([model_ref.cal_beta(int(s), cfg) for s in gold['steps']], dtype=np.float64)
+        assert np.array_equal(got, gold[name])
+
+
+def test_infer_links(tokenizer):
+    gold = load_npz('infer_links.npz')
+    model, _ = small_model(tokenizer, gold)
+    th = float(gold['add_edge_th'])
+    for c in range(int(gold['num_cases'])):
+        g = sub(gold, f'case{c}')
+        groups, p = [], 0
+        for ln in g['groups_len']:
+            groups.append(g['groups_flat'][p:p + ln].tolist())
+            p += ln
+        with torch.no_grad():
+            pairs, conf, etype, order = model.decoder.infer_links(
+                torch.from_numpy(g['z']), torch.from_numpy(g['x']), torch.from_numpy(g['x_pieces']),
+                torch.from_numpy(g['x_pos']), torch.from_numpy(g['edge_index']),
+                torch.from_numpy(g['edge_attr']), groups, th)
+        assert np.array_equal(pairs.numpy(), g['pairs'])
+        np.testing.assert_allclose(conf.numpy(), g['conf'], rtol=1e-5)
+        assert np.array_equal(etype.numpy(), g['etype'])
+        assert order == g['order'].tolist()
+
+
+def test_compact_layout_consistency(tokenizer):
+    """compact_from_reference is index bookkeeping: expanding it back must give the
+    reference batch."""
+    step1 = collate_cases()['zinc_ragged']
+    gold = sub(load_npz('collate_cases.npz'), 'zinc_ragged')
+    batch, _ = collate_ref.collate(step1, gold['uniforms'], piece_pad=tokenizer.pad_idx())
+    c = collate_ref.compact_from_reference(batch)
+    B, N = batch['x'].shape
+    V = c['node_off'][-1]
+    graph_of = np.repeat(np.arange(B), np.diff(c['node_off']))
+    local = np.arange(V) - c['node_off'][graph_of]
+    padded = graph_of * N + local
+    src = np.repeat(np.arange(V), np.diff(c['row_ptr']))
+    assert np.array_equal(padded[src], batch['edge_index'][0])
+    assert np.array_equal(padded[c['col']], batch['edge_index'][1])
+    assert np.array_equal(c['cls'], batch['edge_attr'].argmax(1))
+    sel = np.zeros_like(batch['edge_select'])
+    sel[c['pair_graph'], local[c['pair_src']], local[c['pair_dst']]] = True
+    assert np.array_equal(sel, batch['edge_select'])
+    assert len(c['in_col']) == len(batch['in_piece_edge_idx'])
