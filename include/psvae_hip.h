@@ -1,0 +1,232 @@
+/*
+ * psvae_hip.h — C ABI of libpsvae_hip.so, the gfx950 (MI355X) kernels behind PS-VAE's
+ * training hot path.
+ *
+ * The reference (THUNLP-MT/PS-VAE) is pure Python and has no FFI of its own; each entry
+ * point below names the reference lines whose arithmetic it replaces.  The Python host
+ * side (ps-vae_amd/hip.py) binds these symbols with ctypes and the module classes in
+ * ps-vae_amd/modules mirror the reference's module API on top of them.
+ *
+ * Conventions
+ *   - Every function returns 0 on success, a negative PSVAE_E* code for a rejected
+ *     argument (nothing was launched), or a positive hipError_t from the runtime.
+ *     psvae_last_error() returns a thread-local message for the last non-zero return.
+ *   - All pointers are DEVICE pointers unless a name ends in _host.  The caller owns every
+ *     buffer; the library allocates nothing, keeps no state between calls and is re-entrant.
+ *   - Work is enqueued on `stream` (a hipStream_t passed as void*); nothing synchronises.
+ *   - Matrices are row-major float32; `ld*` are row strides in ELEMENTS.
+ *   - int32 index arrays; bond classes are uint8 (0 = no bond .. 3 = triple,
+ *     reference src/utils/chem_utils.py:15).
+ */
+#ifndef PSVAE_HIP_H
+#define PSVAE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PSVAE_OK 0
+#define PSVAE_EINVAL (-1)      /* bad size / null pointer / misaligned operand        */
+#define PSVAE_ETOOLARGE (-2)   /* a dimension exceeds what the kernel supports         */
+#define PSVAE_EWORKSPACE (-3)  /* workspace_bytes smaller than the *_workspace_bytes() */
+
+#define PSVAE_MAX_ATOMS 250    /* atoms per molecule the collation kernels accept      */
+#define PSVAE_ACT_NONE 0
+#define PSVAE_ACT_RELU 1
+
+int psvae_version(void);
+const char *psvae_last_error(void);
+
+/* ------------------------------------------------------------------------------------
+ * Collation.  Replaces BPEMolDataset.process_step2 + process_step3
+ * (src/data/bpe_dataset.py:56-84, 86-155) on molecules held in the packed layout
+ * (ps-vae_amd/data/packed.py).  One workgroup per molecule builds the n x n bond-class /
+ * same-piece matrix in LDS and walks it row-major, so every output index is the one the
+ * reference's triple loop produces.
+ *
+ * mol_ids [B]            molecules of this batch, in batch order
+ * rng_off [B+1]          prefix sum of n_rng over the batch: the j-th non-bonded candidate
+ *                        pair of molecule b reads uniforms[rng_off[b] + j], which is the
+ *                        order in which the reference calls random() (:129)
+ * keep_prob              0.022 in the reference
+ * ---------------------------------------------------------------------------------- */
+
+/* Pass 1: pair_off[b] = number of kept candidate pairs in molecules 0..b-1 (exclusive
+ * prefix sum, pair_off[B] = P).  pair_cnt [B] is scratch.  N = largest atom count in the
+ * batch (it sizes the LDS matrix). */
+int psvae_collate_count(int B, int N, const int32_t *mol_ids,
+                        const int32_t *atom_off, const int32_t *atom_pos,
+                        const int32_t *bond_off, const int32_t *bond_a, const int32_t *bond_b,
+                        const int32_t *bond_cls,
+                        const int32_t *rng_off, const double *uniforms, double keep_prob,
+                        int32_t *pair_cnt, int32_t *pair_off, void *stream);
+
+/* Pass 2: write the batch.  Any output pointer may be NULL to skip that tensor (all
+ * tensors of one group are skipped or written together).
+ *
+ * Offsets (host-computed prefix sums over the batch, device arrays [B+1]):
+ *   node_off, edge_off, inedge_off, rng_off, pair_off (from pass 1); E = edge_off[B]
+ * Reference layout (shapes / dtypes of the dict process_step3 returns, :142-155):
+ *   x, x_pieces, x_pos int64 [B,N]; atom_mask uint8(bool) [B,N]; pieces int64 [B,S];
+ *   edge_index int64 [2,E] (node id = b*N + m); edge_attr int64 [E,4] one-hot;
+ *   edge_select uint8(bool) [B,N,N]; golden_edge int64 [P]; in_piece_edge_idx int64 [E'];
+ *   props float32 [B,3]
+ * Compact layout (real atoms only, node id = node_off[b] + m):
+ *   cx, cxp, cxpos int32 [V]; row_ptr int32 [V+1], col int32 [E], cls uint8 [E];
+ *   in_row_ptr [V+1], in_col [E'], in_cls [E']; pair_src, pair_dst, pair_graph, golden32 [P]
+ */
+int psvae_collate_fill(int B, int N, int S, const int32_t *mol_ids,
+                       const int32_t *atom_off, const int32_t *atom_type, const int32_t *atom_pos,
+                       const int32_t *bond_off, const int32_t *bond_a, const int32_t *bond_b,
+                       const int32_t *bond_cls,
+                       const int32_t *piece_off, const int32_t *piece_id, const float *props_in,
+                       const int32_t *node_off, const int32_t *edge_off, const int32_t *inedge_off,
+                       const int32_t *rng_off, const int32_t *pair_off, long long E,
+                       const double *uniforms, double keep_prob, int atom_pad, int piece_pad,
+                       /* reference layout */
+                       int64_t *x, int64_t *x_pieces, int64_t *x_pos, uint8_t *atom_mask,
+                       int64_t *pieces, int64_t *edge_index, int64_t *edge_attr, int num_bond_type,
+                       uint8_t *edge_select, int64_t *golden_edge, int64_t *in_piece_edge_idx,
+                       float *props_out,
+                       /* compact layout */
+                       int32_t *cx, int32_t *cxp, int32_t *cxpos,
+                       int32_t *row_ptr, int32_t *col, uint8_t *cls,
+                       int32_t *in_row_ptr, int32_t *in_col, uint8_t *in_cls,
+                       int32_t *pair_src, int32_t *pair_dst, int32_t *pair_graph, int32_t *golden32,
+                       void *stream);
+
+/* out[0] = 0, out[i+1] = in[0] + .. + in[i]  (n <= 2^24) */
+int psvae_exclusive_scan_i32(int n, const int32_t *in, int32_t *out, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * embed_atom: out[v] = [ E_atom[x[v]] | E_piece[xp[v]] | E_pos[xq[v]] ]
+ * (src/modules/vae_piece_decoder.py:65-69).  Backward adds g_out rows into the three
+ * table gradients (float atomics; caller zero-fills them).
+ * ---------------------------------------------------------------------------------- */
+int psvae_embed_atom_fwd(int V, const int32_t *x, const int32_t *xp, const int32_t *xq,
+                         const float *e_atom, int n_atom, int d_atom,
+                         const float *e_piece, int n_piece, int d_piece,
+                         const float *e_pos, int n_pos, int d_pos,
+                         float *out, void *stream);
+int psvae_embed_atom_bwd(int V, const int32_t *x, const int32_t *xp, const int32_t *xq,
+                         const float *g_out, int n_atom, int d_atom, int n_piece, int d_piece,
+                         int n_pos, int d_pos,
+                         float *g_atom, float *g_piece, float *g_pos, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * GINE aggregation, the message/aggregate half of torch_geometric.nn.GINEConv as called at
+ * src/modules/encoder.py:58 with eps = 0:
+ *     out[i] = x[i] + sum over edges e into i of ReLU(x[col[e]] + table[cls[e]])
+ * row_ptr/col/cls: CSR over destination nodes (col = source node of the edge).
+ * table [C,H] = edge_trans applied to the C one-hot rows (src/modules/encoder.py:55).
+ * Requires H % 4 == 0, ld* % 4 == 0 and 16-byte aligned rows.
+ *
+ * Backward, given g = dL/d out and the CSR over SOURCE nodes (t_col = destination):
+ *     g_x[j]     = g[j] + sum over edges e out of j of g[t_col[e]] * [x[j] + table[t_cls[e]] > 0]
+ *     g_table[c] = sum over edges e with class c of the same masked rows
+ * g_table is reduced deterministically through `workspace`
+ * (psvae_gine_aggregate_bwd_workspace_bytes).
+ * ---------------------------------------------------------------------------------- */
+int psvae_gine_aggregate_fwd(int V, int H, int C, const float *x, int ldx, const float *table,
+                             const int32_t *row_ptr, const int32_t *col, const uint8_t *cls,
+                             float *out, int ldo, void *stream);
+size_t psvae_gine_aggregate_bwd_workspace_bytes(int V, int H, int C);
+int psvae_gine_aggregate_bwd(int V, int H, int C, const float *x, int ldx, const float *table,
+                             const float *g, int ldg,
+                             const int32_t *t_row_ptr, const int32_t *t_col, const uint8_t *t_cls,
+                             float *g_x, int ldgx, float *g_table,
+                             void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * f32 matrix product on the matrix cores (v_mfma_f32_32x32x2_f32: exact f32 FMA chains):
+ *     C[m][n] (+)= act( sum_k A(m,k) * B(k,n) + bias[n] )
+ * A(m,k) = A[m*sa_m + k*sa_k], B(k,n) = B[k*sb_k + n*sb_n]: any of the Linear products
+ * (src/modules/common_nn.py:8-23; forward X W^T, input gradient dY W, weight gradient
+ * dY^T X) is one call.  amask (optional, addressed like A) gates A: A(m,k) counts as 0 where
+ * amask(m,k) <= 0 — the ReLU derivative applied to a gradient operand as it is loaded.
+ * bias may be NULL.  accumulate != 0 adds to C.  split_k > 1 reduces partial products
+ * through `workspace` in a fixed order; split_k == 0 lets the library choose.
+ * ---------------------------------------------------------------------------------- */
+size_t psvae_gemm_f32_workspace_bytes(int M, int N, int K, int split_k);
+int psvae_gemm_f32(int M, int N, int K,
+                   const float *A, const float *amask, int64_t sa_m, int64_t sa_k,
+                   const float *B, int64_t sb_k, int64_t sb_n,
+                   float *C, int64_t ldc, const float *bias, int act, int accumulate,
+                   int split_k, void *workspace, size_t workspace_bytes, void *stream);
+
+/* out[n] (+)= sum_m x[m][n] * [mask[m][n] > 0] (mask optional, same ld as x);
+ * deterministic two-stage reduction through `workspace`.  The bias gradient of a Linear. */
+size_t psvae_colsum_workspace_bytes(int M, int N);
+int psvae_colsum_f32(int M, int N, const float *x, const float *mask, int64_t ldx, float *out,
+                     int accumulate, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * embed_graph pooling (src/modules/encoder.py:63-67): out[b] = sum of rows
+ * seg_begin[b] .. seg_end[b]-1 of x.  Backward: g_x[v] = g_out[b] for rows inside segment b
+ * (rows outside every segment are left untouched).  W % 4 == 0.
+ * ---------------------------------------------------------------------------------- */
+int psvae_segment_sum_fwd(int B, int W, const float *x, int ldx, const int32_t *seg_begin,
+                          const int32_t *seg_end, float *out, int ldo, void *stream);
+int psvae_segment_sum_bwd(int B, int W, const float *g_out, int ldgo, const int32_t *seg_begin,
+                          const int32_t *seg_end, float *g_x, int ldgx, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Reparameterised latent (src/modules/vae_piece_decoder.py:56-63) after the two Linears:
+ *     lv = -|lv_pre|;  z = mean + exp(lv/2) * eps;
+ *     kl = -0.5 * sum(1 + lv - mean^2 - exp(lv)) / B
+ * eps is supplied by the caller (the reference draws it with torch.randn_like).
+ * Backward takes g_z [B,L] and the scalar g_kl (device pointer).
+ * ---------------------------------------------------------------------------------- */
+int psvae_rsample_kl_fwd(int B, int L, const float *mean, const float *lv_pre, const float *eps,
+                         float *z, float *kl, void *stream);
+int psvae_rsample_kl_bwd(int B, int L, const float *mean, const float *lv_pre, const float *eps,
+                         const float *g_z, const float *g_kl, float *g_mean, float *g_lv_pre,
+                         void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Link predictor input (src/modules/vae_piece_decoder.py:99-109) without the [B,N,N,*]
+ * intermediates: feats[p] = [ h[src[p]] | h[dst[p]] | z[graph[p]] ], width 2H + L.
+ * Backward sums the rows back per node / per graph without atomics: graph b owns pairs
+ * pair_ptr[b] .. pair_ptr[b+1]-1 and nodes node_begin[b] .. node_end[b]-1.
+ * g_h rows outside every graph's node range are left untouched.
+ * ---------------------------------------------------------------------------------- */
+int psvae_pair_gather_fwd(int P, int H, int L, const float *h, int ldh, const float *z, int ldz,
+                          const int32_t *src, const int32_t *dst, const int32_t *graph,
+                          float *feats, void *stream);
+int psvae_pair_gather_bwd(int B, int H, int L, const float *g_feats,
+                          const int32_t *src, const int32_t *dst, const int32_t *pair_ptr,
+                          const int32_t *node_begin, const int32_t *node_end,
+                          float *g_h, int ldgh, float *g_z, int ldgz, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Last Linear of edge_predictor fused with the link loss
+ * (src/modules/vae_piece_decoder.py:45,54,110,115): logits = hid W^T + b  [P,C], C <= 8;
+ * loss = mean_p( logsumexp(logits[p]) - logits[p][golden[p]] );
+ * dlogits[p] = (softmax(logits[p]) - onehot(golden[p])) / P;
+ * n_correct = #{p : argmax(logits[p]) == golden[p]} (first maximum, as torch.argmax).
+ * P == 0 gives loss = NaN like torch's mean over an empty batch.
+ * psvae_link_ce_bwd_input: g_hid[p][f] = g_loss * sum_c dlogits[p][c] * W[c][f].
+ * ---------------------------------------------------------------------------------- */
+size_t psvae_link_ce_workspace_bytes(int P);
+int psvae_link_ce_fwd(int P, int F, int C, const float *hid, int ldhid, const float *W,
+                      const float *b, const int32_t *golden, float *logits, float *dlogits,
+                      float *loss, int32_t *n_correct,
+                      void *workspace, size_t workspace_bytes, void *stream);
+int psvae_link_ce_bwd_input(int P, int F, int C, const float *dlogits, const float *W,
+                            const float *g_loss, float *g_hid, int ldg, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Inference link prediction (src/modules/vae_piece_decoder.py:233-240):
+ * prob = softmax(logits[p]); conf[p] = max prob, etype[p] = argmax (first maximum);
+ * keep[p] = conf[p] >= add_edge_th && etype[p] != none_bond.
+ * ---------------------------------------------------------------------------------- */
+int psvae_link_infer(int P, int C, const float *logits, float add_edge_th, int none_bond,
+                     float *conf, int32_t *etype, uint8_t *keep, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSVAE_HIP_H */

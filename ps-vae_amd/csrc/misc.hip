@@ -1,0 +1,539 @@
+// The memory-bound helpers around the GEMMs: embedding gather, graph pooling, the
+// reparameterised latent, pair-feature gather / scatter, the fused link loss, column sums.
+#include <stdarg.h>
+
+#include "common.h"
+
+static thread_local char g_last_error[512] = "";
+
+void psvae_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *psvae_last_error(void) { return g_last_error; }
+extern "C" int psvae_version(void) { return 1; }
+
+namespace {
+
+__device__ __forceinline__ float4 add4(float4 a, float4 b) {
+    return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+
+int grid_for(long long items, int threads, int cap = 4096) {
+    long long b = (items + threads - 1) / threads;
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+// ---------------------------------------------------------------- embed_atom
+__global__ void embed_atom_fwd_kernel(int V, const int32_t *__restrict__ x, const int32_t *__restrict__ xp,
+                                      const int32_t *__restrict__ xq, const float *__restrict__ ea, int da,
+                                      const float *__restrict__ ep, int dp, const float *__restrict__ eq, int dq,
+                                      float *__restrict__ out) {
+    const int D = da + dp + dq;
+    const long long total = (long long)V * D;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int v = (int)(i / D), d = (int)(i - (long long)v * D);
+        float val;
+        if (d < da)
+            val = ea[x[v] * da + d];
+        else if (d < da + dp)
+            val = ep[xp[v] * dp + (d - da)];
+        else
+            val = eq[xq[v] * dq + (d - da - dp)];
+        out[i] = val;
+    }
+}
+
+__global__ void embed_atom_bwd_kernel(int V, const int32_t *__restrict__ x, const int32_t *__restrict__ xp,
+                                      const int32_t *__restrict__ xq, const float *__restrict__ g, int da, int dp,
+                                      int dq, float *__restrict__ ga, float *__restrict__ gp, float *__restrict__ gq) {
+    const int D = da + dp + dq;
+    const long long total = (long long)V * D;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int v = (int)(i / D), d = (int)(i - (long long)v * D);
+        const float val = g[i];
+        if (d < da)
+            atomicAdd(&ga[x[v] * da + d], val);
+        else if (d < da + dp)
+            atomicAdd(&gp[xp[v] * dp + (d - da)], val);
+        else
+            atomicAdd(&gq[xq[v] * dq + (d - da - dp)], val);
+    }
+}
+
+// ---------------------------------------------------------------- segment sum (embed_graph)
+__global__ void segment_sum_fwd_kernel(int cols, const float4 *__restrict__ x, int ldx4,
+                                       const int32_t *__restrict__ seg_begin, const int32_t *__restrict__ seg_end,
+                                       float4 *__restrict__ out, int ldo4) {
+    const int b = blockIdx.x;
+    const int r0 = seg_begin[b], r1 = seg_end[b];
+    for (int c = threadIdx.x; c < cols; c += blockDim.x) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int r = r0; r < r1; ++r) acc = add4(acc, x[(long long)r * ldx4 + c]);
+        out[(long long)b * ldo4 + c] = acc;
+    }
+}
+
+__global__ void segment_sum_bwd_kernel(int cols, const float4 *__restrict__ g_out, int ldgo4,
+                                       const int32_t *__restrict__ seg_begin, const int32_t *__restrict__ seg_end,
+                                       float4 *__restrict__ g_x, int ldgx4) {
+    const int b = blockIdx.x;
+    const int r0 = seg_begin[b], r1 = seg_end[b];
+    for (int c = threadIdx.x; c < cols; c += blockDim.x) {
+        const float4 v = g_out[(long long)b * ldgo4 + c];
+        for (int r = r0; r < r1; ++r) g_x[(long long)r * ldgx4 + c] = v;
+    }
+}
+
+// ---------------------------------------------------------------- rsample + KL
+__global__ __launch_bounds__(1024) void rsample_kl_fwd_kernel(int B, int L, const float *__restrict__ mean,
+                                                              const float *__restrict__ lv_pre,
+                                                              const float *__restrict__ eps, float *__restrict__ z,
+                                                              float *__restrict__ kl) {
+    __shared__ float sh[1024];
+    const int total = B * L;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < total; i += 1024) {
+        const float m = mean[i];
+        const float lv = -fabsf(lv_pre[i]);
+        s += 1.0f + lv - m * m - expf(lv);
+        z[i] = m + expf(lv / 2) * eps[i];
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = 512; d > 0; d >>= 1) {
+        if (threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *kl = -0.5f * sh[0] / (float)B;
+}
+
+__global__ void rsample_kl_bwd_kernel(int B, int L, const float *__restrict__ mean, const float *__restrict__ lv_pre,
+                                      const float *__restrict__ eps, const float *__restrict__ g_z,
+                                      const float *__restrict__ g_kl, float *__restrict__ g_mean,
+                                      float *__restrict__ g_lv_pre) {
+    const int total = B * L;
+    const float gk = g_kl ? *g_kl : 0.f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const float m = mean[i], pre = lv_pre[i];
+        const float lv = -fabsf(pre);
+        const float gz = g_z ? g_z[i] : 0.f;
+        // d kl / d mean = mean / B ; d kl / d lv = -0.5 (1 - exp(lv)) / B
+        g_mean[i] = gz + gk * m / (float)B;
+        const float g_lv = gz * 0.5f * expf(lv / 2) * eps[i] + gk * (-0.5f) * (1.0f - expf(lv)) / (float)B;
+        const float sgn = pre > 0.f ? 1.f : (pre < 0.f ? -1.f : 0.f);   // d(-|u|)/du = -sign(u)
+        g_lv_pre[i] = -sgn * g_lv;
+    }
+}
+
+// ---------------------------------------------------------------- pair features
+__global__ void pair_gather_fwd_kernel(int P, int h4, int l4, const float4 *__restrict__ h, int ldh4,
+                                       const float4 *__restrict__ z, int ldz4, const int32_t *__restrict__ src,
+                                       const int32_t *__restrict__ dst, const int32_t *__restrict__ graph,
+                                       float4 *__restrict__ feats) {
+    const int w4 = 2 * h4 + l4;
+    const long long total = (long long)P * w4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int p = (int)(i / w4), c = (int)(i - (long long)p * w4);
+        float4 v;
+        if (c < h4)
+            v = h[(long long)src[p] * ldh4 + c];
+        else if (c < 2 * h4)
+            v = h[(long long)dst[p] * ldh4 + (c - h4)];
+        else
+            v = z[(long long)graph[p] * ldz4 + (c - 2 * h4)];
+        feats[i] = v;
+    }
+}
+
+// One workgroup per graph.  Pairs of the graph are staged CHUNK at a time in LDS (node ids
+// local to the graph); thread (slot, c) sums column c of the matching feature rows for nodes
+// slot, slot+slots, ...  The order of the sum is the pair order: deterministic.
+constexpr int PAIR_CHUNK = 1024;
+__global__ void pair_gather_bwd_kernel(int h4, int l4, int slots, const float4 *__restrict__ g_feats,
+                                       const int32_t *__restrict__ src, const int32_t *__restrict__ dst,
+                                       const int32_t *__restrict__ pair_ptr, const int32_t *__restrict__ node_begin,
+                                       const int32_t *__restrict__ node_end, float4 *__restrict__ g_h, int ldgh4,
+                                       float4 *__restrict__ g_z, int ldgz4) {
+    __shared__ int s_src[PAIR_CHUNK], s_dst[PAIR_CHUNK];
+    const int b = blockIdx.x;
+    const int p0 = pair_ptr[b], p1 = pair_ptr[b + 1];
+    const int n0 = node_begin[b], n1 = node_end[b];
+    const int w4 = 2 * h4 + l4;
+    const int c = threadIdx.x % h4, slot = threadIdx.x / h4;
+    const bool active = slot < slots;
+    float4 zacc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool zthread = (int)threadIdx.x < l4;
+    bool first = true;
+    int pc = p0;
+    do {   // runs once even without pairs so that g_h / g_z are written
+        const int cnt = min(PAIR_CHUNK, p1 - pc);
+        __syncthreads();
+        for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+            s_src[i] = src[pc + i] - n0;
+            s_dst[i] = dst[pc + i] - n0;
+        }
+        __syncthreads();
+        if (active) {
+            for (int j = slot; j < n1 - n0; j += slots) {
+                float4 acc = first ? make_float4(0.f, 0.f, 0.f, 0.f) : g_h[(long long)(n0 + j) * ldgh4 + c];
+                for (int i = 0; i < cnt; ++i) {
+                    if (s_src[i] == j) acc = add4(acc, g_feats[(long long)(pc + i) * w4 + c]);
+                    if (s_dst[i] == j) acc = add4(acc, g_feats[(long long)(pc + i) * w4 + h4 + c]);
+                }
+                g_h[(long long)(n0 + j) * ldgh4 + c] = acc;
+            }
+        }
+        if (zthread)
+            for (int i = 0; i < cnt; ++i) zacc = add4(zacc, g_feats[(long long)(pc + i) * w4 + 2 * h4 + threadIdx.x]);
+        first = false;
+        pc += cnt;
+    } while (pc < p1);
+    if (zthread) g_z[(long long)b * ldgz4 + threadIdx.x] = zacc;
+}
+
+// ---------------------------------------------------------------- link loss
+template <int MAXC>
+__global__ __launch_bounds__(256) void link_ce_fwd_kernel(int P, int F, int C, const float *__restrict__ hid,
+                                                          int ldhid, const float *__restrict__ W,
+                                                          const float *__restrict__ bias,
+                                                          const int32_t *__restrict__ golden,
+                                                          float *__restrict__ logits, float *__restrict__ dlogits,
+                                                          float *__restrict__ part_loss, int *__restrict__ part_ok) {
+    __shared__ float sh_loss[4];
+    __shared__ int sh_ok[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float loss_acc = 0.f;
+    int ok_acc = 0;
+    for (int p = blockIdx.x * 4 + wave; p < P; p += gridDim.x * 4) {
+        float dot[MAXC];
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) dot[c] = 0.f;
+        const float *row = hid + (long long)p * ldhid;
+        for (int f = lane; f < F; f += 64) {
+            const float hv = row[f];
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c)
+                if (c < C) dot[c] += hv * W[c * F + f];
+        }
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) dot[c] += __shfl_xor(dot[c], d);
+        if (lane == 0) {
+            float mx = -INFINITY;
+            int arg = 0;
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c)
+                if (c < C) {
+                    dot[c] += bias ? bias[c] : 0.f;
+                    if (dot[c] > mx) mx = dot[c], arg = c;
+                }
+            float se = 0.f;
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c)
+                if (c < C) se += expf(dot[c] - mx);
+            const float lse = mx + logf(se);
+            const int gold = golden[p];
+            float lg = 0.f;
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c)
+                if (c < C) {
+                    if (c == gold) lg = dot[c];
+                    logits[(long long)p * C + c] = dot[c];
+                    dlogits[(long long)p * C + c] = (expf(dot[c] - lse) - (c == gold ? 1.f : 0.f)) / (float)P;
+                }
+            loss_acc += lse - lg;
+            ok_acc += (arg == gold);
+        }
+    }
+    if (lane == 0) sh_loss[wave] = loss_acc, sh_ok[wave] = ok_acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part_loss[blockIdx.x] = ((sh_loss[0] + sh_loss[1]) + sh_loss[2]) + sh_loss[3];
+        part_ok[blockIdx.x] = sh_ok[0] + sh_ok[1] + sh_ok[2] + sh_ok[3];
+    }
+}
+
+__global__ void link_ce_finish_kernel(int P, int n_part, const float *__restrict__ part_loss,
+                                      const int *__restrict__ part_ok, float *__restrict__ loss,
+                                      int32_t *__restrict__ n_correct) {
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        int ok = 0;
+        for (int i = 0; i < n_part; ++i) s += part_loss[i], ok += part_ok[i];
+        *loss = s / (float)P;   // 0/0 = NaN for P == 0, as torch's mean over no rows
+        if (n_correct) *n_correct = ok;
+    }
+}
+
+__global__ void link_ce_bwd_input_kernel(int P, int F, int C, const float *__restrict__ dlogits,
+                                         const float *__restrict__ W, const float *__restrict__ g_loss,
+                                         float *__restrict__ g_hid, int ldg) {
+    const float gl = *g_loss;
+    const long long total = (long long)P * F;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int p = (int)(i / F), f = (int)(i - (long long)p * F);
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s += dlogits[(long long)p * C + c] * W[c * F + f];
+        g_hid[(long long)p * ldg + f] = gl * s;
+    }
+}
+
+__global__ void link_infer_kernel(int P, int C, const float *__restrict__ logits, float th, int none_bond,
+                                  float *__restrict__ conf, int32_t *__restrict__ etype, uint8_t *__restrict__ keep) {
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        const float *l = logits + (long long)p * C;
+        float mx = l[0];
+        int arg = 0;
+        for (int c = 1; c < C; ++c)
+            if (l[c] > mx) mx = l[c], arg = c;
+        float se = 0.f;
+        for (int c = 0; c < C; ++c) se += expf(l[c] - mx);
+        const float cf = 1.0f / se;   // softmax value of the maximum
+        conf[p] = cf;
+        etype[p] = arg;
+        keep[p] = (cf >= th && arg != none_bond) ? 1 : 0;
+    }
+}
+
+// ---------------------------------------------------------------- column sums
+__global__ void colsum_partial_kernel(int M, int N, int rows_per_block, const float *__restrict__ x,
+                                      const float *__restrict__ mask, long long ldx, float *__restrict__ partial) {
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        float s = 0.f;
+        if (mask)
+            for (int r = r0; r < r1; ++r) s += mask[(long long)r * ldx + n] > 0.f ? x[(long long)r * ldx + n] : 0.f;
+        else
+            for (int r = r0; r < r1; ++r) s += x[(long long)r * ldx + n];
+        partial[(long long)blockIdx.x * N + n] = s;
+    }
+}
+
+__global__ void colsum_finish_kernel(int N, int n_part, const float *__restrict__ partial, float *__restrict__ out,
+                                     int accumulate) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int b = 0; b < n_part; ++b) s += partial[(long long)b * N + n];
+    out[n] = accumulate ? out[n] + s : s;
+}
+
+constexpr int COLSUM_MAX_BLOCKS = 512;
+int colsum_rows_per_block(int M) {
+    int r = psvae_cdiv(M, COLSUM_MAX_BLOCKS);
+    return r < 32 ? 32 : r;
+}
+
+constexpr int LINK_CE_MAX_BLOCKS = 1024;
+int link_ce_blocks(int P) {
+    int b = psvae_cdiv(P, 4);
+    return b < 1 ? 1 : (b > LINK_CE_MAX_BLOCKS ? LINK_CE_MAX_BLOCKS : b);
+}
+
+}  // namespace
+
+extern "C" int psvae_embed_atom_fwd(int V, const int32_t *x, const int32_t *xp, const int32_t *xq,
+                                    const float *e_atom, int n_atom, int d_atom, const float *e_piece, int n_piece,
+                                    int d_piece, const float *e_pos, int n_pos, int d_pos, float *out, void *stream) {
+    PSVAE_REQUIRE(V >= 0 && d_atom >= 0 && d_piece >= 0 && d_pos >= 0, PSVAE_EINVAL, "psvae_embed_atom_fwd: bad sizes");
+    (void)n_atom, (void)n_piece, (void)n_pos;
+    const long long total = (long long)V * (d_atom + d_piece + d_pos);
+    if (total == 0) return PSVAE_OK;
+    PSVAE_REQUIRE(x && xp && xq && e_atom && e_piece && e_pos && out, PSVAE_EINVAL, "psvae_embed_atom_fwd: null pointer");
+    hipLaunchKernelGGL(embed_atom_fwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, V, x, xp,
+                       xq, e_atom, d_atom, e_piece, d_piece, e_pos, d_pos, out);
+    PSVAE_CHECK_LAUNCH("psvae_embed_atom_fwd");
+    return PSVAE_OK;
+}
+
+extern "C" int psvae_embed_atom_bwd(int V, const int32_t *x, const int32_t *xp, const int32_t *xq, const float *g_out,
+                                    int n_atom, int d_atom, int n_piece, int d_piece, int n_pos, int d_pos,
+                                    float *g_atom, float *g_piece, float *g_pos, void *stream) {
+    PSVAE_REQUIRE(V >= 0 && d_atom >= 0 && d_piece >= 0 && d_pos >= 0, PSVAE_EINVAL, "psvae_embed_atom_bwd: bad sizes");
+    (void)n_atom, (void)n_piece, (void)n_pos;
+    const long long total = (long long)V * (d_atom + d_piece + d_pos);
+    if (total == 0) return PSVAE_OK;
+    PSVAE_REQUIRE(x && xp && xq && g_out && g_atom && g_piece && g_pos, PSVAE_EINVAL, "psvae_embed_atom_bwd: null pointer");
+    hipLaunchKernelGGL(embed_atom_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, V, x, xp,
+                       xq, g_out, d_atom, d_piece, d_pos, g_atom, g_piece, g_pos);
+    PSVAE_CHECK_LAUNCH("psvae_embed_atom_bwd");
+    return PSVAE_OK;
+}
+
+static int check_seg(const char *fn, int B, int W, const void *a, int lda, const void *b, int ldb, const void *s0,
+                     const void *s1) {
+    PSVAE_REQUIRE(B >= 0 && W > 0 && W % 4 == 0, PSVAE_EINVAL, "%s: W=%d must be a positive multiple of 4", fn, W);
+    if (B == 0) return PSVAE_OK;
+    PSVAE_REQUIRE(a && b && s0 && s1 && psvae_aligned16(a) && psvae_aligned16(b), PSVAE_EINVAL,
+                  "%s: null or misaligned operand", fn);
+    PSVAE_REQUIRE(lda % 4 == 0 && lda >= W && ldb % 4 == 0 && ldb >= W, PSVAE_EINVAL, "%s: bad row stride", fn);
+    return PSVAE_OK;
+}
+
+extern "C" int psvae_segment_sum_fwd(int B, int W, const float *x, int ldx, const int32_t *seg_begin,
+                                     const int32_t *seg_end, float *out, int ldo, void *stream) {
+    int rc = check_seg("psvae_segment_sum_fwd", B, W, x, ldx, out, ldo, seg_begin, seg_end);
+    if (rc || B == 0) return rc;
+    const int cols = W / 4, threads = cols >= 256 ? 256 : psvae_cdiv(cols, 64) * 64;
+    hipLaunchKernelGGL(segment_sum_fwd_kernel, dim3(B), dim3(threads), 0, (hipStream_t)stream, cols,
+                       (const float4 *)x, ldx / 4, seg_begin, seg_end, (float4 *)out, ldo / 4);
+    PSVAE_CHECK_LAUNCH("psvae_segment_sum_fwd");
+    return PSVAE_OK;
+}
+
+extern "C" int psvae_segment_sum_bwd(int B, int W, const float *g_out, int ldgo, const int32_t *seg_begin,
+                                     const int32_t *seg_end, float *g_x, int ldgx, void *stream) {
+    int rc = check_seg("psvae_segment_sum_bwd", B, W, g_out, ldgo, g_x, ldgx, seg_begin, seg_end);
+    if (rc || B == 0) return rc;
+    const int cols = W / 4, threads = cols >= 256 ? 256 : psvae_cdiv(cols, 64) * 64;
+    hipLaunchKernelGGL(segment_sum_bwd_kernel, dim3(B), dim3(threads), 0, (hipStream_t)stream, cols,
+                       (const float4 *)g_out, ldgo / 4, seg_begin, seg_end, (float4 *)g_x, ldgx / 4);
+    PSVAE_CHECK_LAUNCH("psvae_segment_sum_bwd");
+    return PSVAE_OK;
+}
+
+extern "C" int psvae_rsample_kl_fwd(int B, int L, const float *mean, const float *lv_pre, const float *eps, float *z,
+                                    float *kl, void *stream) {
+    PSVAE_REQUIRE(B > 0 && L > 0 && (long long)B * L < (1ll << 31), PSVAE_EINVAL, "psvae_rsample_kl_fwd: bad sizes");
+    PSVAE_REQUIRE(mean && lv_pre && eps && z && kl, PSVAE_EINVAL, "psvae_rsample_kl_fwd: null pointer");
+    hipLaunchKernelGGL(rsample_kl_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, B, L, mean, lv_pre, eps, z, kl);
+    PSVAE_CHECK_LAUNCH("psvae_rsample_kl_fwd");
+    return PSVAE_OK;
+}
+
+extern "C" int psvae_rsample_kl_bwd(int B, int L, const float *mean, const float *lv_pre, const float *eps,
+                                    const float *g_z, const float *g_kl, float *g_mean, float *g_lv_pre,
+                                    void *stream) {
+    PSVAE_REQUIRE(B > 0 && L > 0 && (long long)B * L < (1ll << 31), PSVAE_EINVAL, "psvae_rsample_kl_bwd: bad sizes");
+    PSVAE_REQUIRE(mean && lv_pre && eps && g_mean && g_lv_pre, PSVAE_EINVAL, "psvae_rsample_kl_bwd: null pointer");
+    hipLaunchKernelGGL(rsample_kl_bwd_kernel, dim3(grid_for((long long)B * L, 256)), dim3(256), 0, (hipStream_t)stream,
+                       B, L, mean, lv_pre, eps, g_z, g_kl, g_mean, g_lv_pre);
+    PSVAE_CHECK_LAUNCH("psvae_rsample_kl_bwd");
+    return PSVAE_OK;
+}
+
+extern "C" int psvae_pair_gather_fwd(int P, int H, int L, const float *h, int ldh, const float *z, int ldz,
+                                     const int32_t *src, const int32_t *dst, const int32_t *graph, float *feats,
+                                     void *stream) {
+    PSVAE_REQUIRE(P >= 0 && H > 0 && L > 0 && H % 4 == 0 && L % 4 == 0, PSVAE_EINVAL,
+                  "psvae_pair_gather_fwd: H=%d and L=%d must be positive multiples of 4", H, L);
+    if (P == 0) return PSVAE_OK;
+    PSVAE_REQUIRE(h && z && src && dst && graph && feats && psvae_aligned16(h) && psvae_aligned16(z) &&
+                      psvae_aligned16(feats), PSVAE_EINVAL, "psvae_pair_gather_fwd: null or misaligned operand");
+    PSVAE_REQUIRE(ldh % 4 == 0 && ldh >= H && ldz % 4 == 0 && ldz >= L, PSVAE_EINVAL, "psvae_pair_gather_fwd: bad stride");
+    const long long total = (long long)P * (2 * H + L) / 4;
+    hipLaunchKernelGGL(pair_gather_fwd_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, (hipStream_t)stream, P,
+                       H / 4, L / 4, (const float4 *)h, ldh / 4, (const float4 *)z, ldz / 4, src, dst, graph,
+                       (float4 *)feats);
+    PSVAE_CHECK_LAUNCH("psvae_pair_gather_fwd");
+    return PSVAE_OK;
+}
+
+extern "C" int psvae_pair_gather_bwd(int B, int H, int L, const float *g_feats, const int32_t *src, const int32_t *dst,
+                                     const int32_t *pair_ptr, const int32_t *node_begin, const int32_t *node_end,
+                                     float *g_h, int ldgh, float *g_z, int ldgz, void *stream) {
+    PSVAE_REQUIRE(B >= 0 && H > 0 && L > 0 && H % 4 == 0 && L % 4 == 0, PSVAE_EINVAL,
+                  "psvae_pair_gather_bwd: H=%d and L=%d must be positive multiples of 4", H, L);
+    if (B == 0) return PSVAE_OK;
+    PSVAE_REQUIRE(pair_ptr && node_begin && node_end && g_h && g_z && psvae_aligned16(g_h) && psvae_aligned16(g_z) &&
+                      (g_feats == nullptr || psvae_aligned16(g_feats)), PSVAE_EINVAL,
+                  "psvae_pair_gather_bwd: null or misaligned operand");
+    PSVAE_REQUIRE(ldgh % 4 == 0 && ldgh >= H && ldgz % 4 == 0 && ldgz >= L, PSVAE_EINVAL, "psvae_pair_gather_bwd: bad stride");
+    const int h4 = H / 4, l4 = L / 4;
+    PSVAE_REQUIRE(h4 <= 1024 && l4 <= 64, PSVAE_ETOOLARGE, "psvae_pair_gather_bwd: H or L too wide");
+    int slots = h4 >= 256 ? 1 : psvae_cdiv(256, h4);
+    int threads = psvae_cdiv(h4 * slots, 64) * 64;
+    if (threads > 1024) slots = 1024 / h4, threads = psvae_cdiv(h4 * slots, 64) * 64;
+    hipLaunchKernelGGL(pair_gather_bwd_kernel, dim3(B), dim3(threads), 0, (hipStream_t)stream, h4, l4, slots,
+                       (const float4 *)g_feats, src, dst, pair_ptr, node_begin, node_end, (float4 *)g_h, ldgh / 4,
+                       (float4 *)g_z, ldgz / 4);
+    PSVAE_CHECK_LAUNCH("psvae_pair_gather_bwd");
+    return PSVAE_OK;
+}
+
+extern "C" size_t psvae_link_ce_workspace_bytes(int P) {
+    return (size_t)link_ce_blocks(P) * (sizeof(float) + sizeof(int));
+}
+
+extern "C" int psvae_link_ce_fwd(int P, int F, int C, const float *hid, int ldhid, const float *W, const float *b,
+                                 const int32_t *golden, float *logits, float *dlogits, float *loss, int32_t *n_correct,
+                                 void *workspace, size_t workspace_bytes, void *stream) {
+    PSVAE_REQUIRE(P >= 0 && F > 0 && C > 0, PSVAE_EINVAL, "psvae_link_ce_fwd: bad sizes");
+    PSVAE_REQUIRE(C <= 8, PSVAE_ETOOLARGE, "psvae_link_ce_fwd: at most 8 classes (C=%d)", C);
+    PSVAE_REQUIRE(loss != nullptr && W != nullptr, PSVAE_EINVAL, "psvae_link_ce_fwd: null pointer");
+    PSVAE_REQUIRE(workspace && workspace_bytes >= psvae_link_ce_workspace_bytes(P), PSVAE_EWORKSPACE,
+                  "psvae_link_ce_fwd: workspace too small");
+    PSVAE_REQUIRE(P == 0 || (hid && golden && logits && dlogits && ldhid >= F), PSVAE_EINVAL,
+                  "psvae_link_ce_fwd: null pointer or ldhid < F");
+    const int blocks = link_ce_blocks(P);
+    float *part_loss = (float *)workspace;
+    int *part_ok = (int *)(part_loss + blocks);
+    hipStream_t s = (hipStream_t)stream;
+    if (C <= 4)
+        hipLaunchKernelGGL(link_ce_fwd_kernel<4>, dim3(blocks), dim3(256), 0, s, P, F, C, hid, ldhid, W, b, golden,
+                           logits, dlogits, part_loss, part_ok);
+    else
+        hipLaunchKernelGGL(link_ce_fwd_kernel<8>, dim3(blocks), dim3(256), 0, s, P, F, C, hid, ldhid, W, b, golden,
+                           logits, dlogits, part_loss, part_ok);
+    PSVAE_CHECK_LAUNCH("psvae_link_ce_fwd");
+    hipLaunchKernelGGL(link_ce_finish_kernel, dim3(1), dim3(64), 0, s, P, blocks, part_loss, part_ok, loss, n_correct);
+    PSVAE_CHECK_LAUNCH("psvae_link_ce_fwd (finish)");
+    return PSVAE_OK;
+}
+
+extern "C" int psvae_link_ce_bwd_input(int P, int F, int C, const float *dlogits, const float *W, const float *g_loss,
+                                       float *g_hid, int ldg, void *stream) {
+    PSVAE_REQUIRE(P >= 0 && F > 0 && C > 0 && ldg >= F, PSVAE_EINVAL, "psvae_link_ce_bwd_input: bad sizes");
+    if (P == 0) return PSVAE_OK;
+    PSVAE_REQUIRE(dlogits && W && g_loss && g_hid, PSVAE_EINVAL, "psvae_link_ce_bwd_input: null pointer");
+    hipLaunchKernelGGL(link_ce_bwd_input_kernel, dim3(grid_for((long long)P * F, 256, 8192)), dim3(256), 0,
+                       (hipStream_t)stream, P, F, C, dlogits, W, g_loss, g_hid, ldg);
+    PSVAE_CHECK_LAUNCH("psvae_link_ce_bwd_input");
+    return PSVAE_OK;
+}
+
+extern "C" int psvae_link_infer(int P, int C, const float *logits, float add_edge_th, int none_bond, float *conf,
+                                int32_t *etype, uint8_t *keep, void *stream) {
+    PSVAE_REQUIRE(P >= 0 && C > 0, PSVAE_EINVAL, "psvae_link_infer: bad sizes");
+    if (P == 0) return PSVAE_OK;
+    PSVAE_REQUIRE(logits && conf && etype && keep, PSVAE_EINVAL, "psvae_link_infer: null pointer");
+    hipLaunchKernelGGL(link_infer_kernel, dim3(grid_for(P, 256)), dim3(256), 0, (hipStream_t)stream, P, C, logits,
+                       add_edge_th, none_bond, conf, etype, keep);
+    PSVAE_CHECK_LAUNCH("psvae_link_infer");
+    return PSVAE_OK;
+}
+
+extern "C" size_t psvae_colsum_workspace_bytes(int M, int N) {
+    if (M <= 0 || N <= 0) return 0;
+    return (size_t)psvae_cdiv(M, colsum_rows_per_block(M)) * N * sizeof(float);
+}
+
+extern "C" int psvae_colsum_f32(int M, int N, const float *x, const float *mask, int64_t ldx, float *out,
+                                int accumulate, void *workspace, size_t workspace_bytes, void *stream) {
+    PSVAE_REQUIRE(M >= 0 && N >= 0, PSVAE_EINVAL, "psvae_colsum_f32: bad sizes");
+    if (N == 0) return PSVAE_OK;
+    PSVAE_REQUIRE(out != nullptr, PSVAE_EINVAL, "psvae_colsum_f32: out is null");
+    hipStream_t s = (hipStream_t)stream;
+    if (M == 0) return accumulate ? PSVAE_OK : (int)hipMemsetAsync(out, 0, (size_t)N * sizeof(float), s);
+    PSVAE_REQUIRE(x != nullptr && ldx >= N, PSVAE_EINVAL, "psvae_colsum_f32: x null or ldx < N");
+    PSVAE_REQUIRE(workspace && workspace_bytes >= psvae_colsum_workspace_bytes(M, N), PSVAE_EWORKSPACE,
+                  "psvae_colsum_f32: workspace too small");
+    const int rpb = colsum_rows_per_block(M), blocks = psvae_cdiv(M, rpb);
+    const int threads = N >= 256 ? 256 : psvae_cdiv(N, 64) * 64;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(blocks), dim3(threads), 0, s, M, N, rpb, x, mask, (long long)ldx,
+                       (float *)workspace);
+    PSVAE_CHECK_LAUNCH("psvae_colsum_f32");
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3(psvae_cdiv(N, 256)), dim3(256), 0, s, N, blocks,
+                       (const float *)workspace, out, accumulate);
+    PSVAE_CHECK_LAUNCH("psvae_colsum_f32 (finish)");
+    return PSVAE_OK;
+}

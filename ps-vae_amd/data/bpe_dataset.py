@@ -1,0 +1,101 @@
+"""BPEMolDataset / get_dataloader with the reference's names
+(src/data/bpe_dataset.py:19-187); collation runs on the GPU.
+
+The dataset holds the molecules in the packed layout (data/packed.py) on the device.
+process_step1 (RDKit -> raw dict, :30-54) is outside the path: a dataset is built from a
+list of process_step1 dicts or from a packed .npz file."""
+import os
+import random
+
+import numpy as np
+import torch
+
+from .collate import collate_packed
+from .packed import PackedMolecules
+
+
+class BPEMolDataset(torch.utils.data.Dataset):
+    def __init__(self, fname, tokenizer, device='cuda', data=None):
+        """fname: a packed .npz (PackedMolecules.save) or a torch-saved list of process_step1
+        dicts ('processed_data.pkl' in the reference, :23-26, loaded with weights_only=True);
+        `data` passes the list directly."""
+        super(BPEMolDataset, self).__init__()
+        self.tokenizer = tokenizer
+        self.device = torch.device(device)
+        if data is None:
+            if fname.endswith('.npz'):
+                self.packed = PackedMolecules.load(fname)
+            else:
+                root, _ = os.path.split(fname)
+                data = torch.load(os.path.join(root, 'processed_data.pkl'), weights_only=True)
+        if data is not None:
+            self.packed = data if isinstance(data, PackedMolecules) else PackedMolecules.from_step1(data)
+        self.dpacked = self.packed.to_device(self.device)
+
+    @staticmethod
+    def process_step2(data, tokenizer):
+        """Reference :56-84 expands a molecule to dense n x n Python lists.  Here that work is
+        deferred to the collation kernel: this returns the O(n) per-atom fields and keeps the
+        raw dict for process_step3."""
+        n = len(data['x'])
+        x_pieces, x_pos = [0] * n, [0] * n
+        for pos, group in enumerate(data['groups']):
+            for aid in group:
+                x_pieces[aid] = data['pieces'][pos]
+                x_pos[aid] = pos
+        return {'x': data['x'], 'props': data['props'], 'pieces': data['pieces'], 'x_pieces': x_pieces,
+                'x_pos': x_pos, 'step1': data}
+
+    @staticmethod
+    def process_step3(data_list, tokenizer, device='cuda', uniforms=None):
+        """Collate process_step2 results (reference :86-155).  The acceptance draws come from
+        Python's `random.random()` in the reference's order, so under the same random.seed
+        this returns the reference's batch bit for bit; pass `uniforms` (float64 device
+        tensor) to supply them instead."""
+        packed = PackedMolecules.from_step1([d['step1'] for d in data_list])
+        dpacked = packed.to_device(device)
+        if uniforms is None:
+            need = int(packed.n_rng.sum())
+            uniforms = torch.tensor([random.random() for _ in range(need)] or [0.0], dtype=torch.float64).to(device)
+        return collate_packed(dpacked, np.arange(len(packed)), uniforms=uniforms,
+                              atom_pad=tokenizer.atom_pad_idx(), piece_pad=tokenizer.pad_idx(),
+                              num_bond_type=tokenizer.chem_vocab.num_bond_type())
+
+    def collate_ids(self, ids, uniforms=None, reference_layout=False, generator=None):
+        """Collate molecules `ids` of this dataset straight from the packed device arrays."""
+        return collate_packed(self.dpacked, ids, uniforms=uniforms, atom_pad=self.tokenizer.atom_pad_idx(),
+                              piece_pad=self.tokenizer.pad_idx(),
+                              num_bond_type=self.tokenizer.chem_vocab.num_bond_type(),
+                              reference_layout=reference_layout, generator=generator)
+
+    def __getitem__(self, idx):
+        return int(idx)
+
+    def __len__(self):
+        return len(self.packed)
+
+    def collate_fn(self, data_list):
+        return self.collate_ids(np.asarray(data_list, dtype=np.int64), reference_layout=True)
+
+
+class _Loader:
+    """Batches of molecule ids collated on the GPU (the DataLoader + worker processes of
+    the reference, :184-187, are not needed: there is no per-sample Python work left)."""
+
+    def __init__(self, dataset, batch_size, shuffle, reference_layout=True, seed=None):
+        self.dataset, self.batch_size, self.shuffle = dataset, batch_size, shuffle
+        self.reference_layout = reference_layout
+        self.rng = np.random.default_rng(seed)
+
+    def __len__(self):
+        return (len(self.dataset) + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        order = self.rng.permutation(len(self.dataset)) if self.shuffle else np.arange(len(self.dataset))
+        for i in range(0, len(order), self.batch_size):
+            yield self.dataset.collate_ids(order[i:i + self.batch_size], reference_layout=self.reference_layout)
+
+
+def get_dataloader(fname, tokenizer, batch_size, shuffle=False, num_workers=4, device='cuda', data=None):
+    dataset = BPEMolDataset(fname, tokenizer, device=device, data=data)
+    return _Loader(dataset, batch_size, shuffle)

@@ -1,0 +1,127 @@
+"""Batch collation on the GPU: host-side planning around the two collation kernels.
+
+Replaces the DataLoader's __getitem__ + collate_fn of the reference
+(src/data/bpe_dataset.py:56-155, 173-181).  The host only prefix-sums per-molecule counts
+(a few numpy cumsums over the batch); all per-atom / per-cell work runs in
+psvae_collate_count / psvae_collate_fill.  One device->host read per batch returns P, the
+number of kept candidate pairs, which sizes golden_edge exactly as the reference does.
+"""
+import numpy as np
+import torch
+
+from .. import hip, ops
+
+KEEP_PROB = 0.022   # src/data/bpe_dataset.py:129
+
+
+class CompactBatch:
+    """Real atoms only; node id = node_off[b] + m.  See include/psvae_hip.h (psvae_collate_fill)."""
+
+    def __init__(self, t, node_off, pair_off, num_graphs):
+        self.cx, self.cxp, self.cxpos = t['cx'], t['cxp'], t['cxpos']
+        self.node_off, self.pair_off = node_off, pair_off
+        self.csr = ops.Csr(t['row_ptr'], t['col'], t['cls'])
+        self.csr_in = ops.Csr(t['in_row_ptr'], t['in_col'], t['in_cls'])
+        self.segments = ops.Segments.from_offsets(node_off)
+        self.pairs = ops.PairList(t['pair_src'], t['pair_dst'], t['pair_graph'], pair_off, self.segments)
+        self.golden = t['golden32']
+        self.num_graphs = num_graphs
+
+    @property
+    def num_nodes(self):
+        return self.cx.numel()
+
+
+class CollatedBatch(dict):
+    """The reference's batch dict (keys of src/data/bpe_dataset.py:142-155, present when the
+    reference layout was requested) plus `.compact` (CompactBatch or None), `.pieces`,
+    `.props`, `.batch_size`."""
+    compact = None
+
+
+def plan(host, ids):
+    """Shapes and prefix sums of a batch from the per-molecule counts (host numpy)."""
+    ids = np.asarray(ids, dtype=np.int64)
+    n_atoms = (host.atom_off[ids + 1] - host.atom_off[ids]).astype(np.int64)
+    n_pieces = (host.piece_off[ids + 1] - host.piece_off[ids]).astype(np.int64)
+    B = len(ids)
+    offs = np.zeros((5, B + 1), dtype=np.int64)
+    offs[0, 1:] = np.cumsum(n_atoms)
+    offs[1, 1:] = np.cumsum(host.n_edge[ids])
+    offs[2, 1:] = np.cumsum(host.n_inpiece[ids])
+    offs[3, 1:] = np.cumsum(host.n_rng[ids])
+    offs[4, :B] = ids
+    if offs.max(initial=0) >= 2 ** 31:
+        raise ValueError('batch too large for int32 offsets')
+    return {'B': B, 'N': int(n_atoms.max(initial=0)), 'S': int(n_pieces.max(initial=0)),
+            'V': int(offs[0, -1]), 'E': int(offs[1, -1]), 'Ein': int(offs[2, -1]), 'R': int(offs[3, -1]),
+            'offs': offs.astype(np.int32)}
+
+
+def collate_packed(dpacked, ids, uniforms=None, atom_pad=10, piece_pad=300, num_bond_type=4,
+                   keep_prob=KEEP_PROB, reference_layout=True, compact_layout=True, generator=None):
+    """Collate molecules `ids` of a DevicePackedMolecules.
+
+    uniforms: float64 device tensor with at least R = sum(n_rng) entries, consumed in the
+    order the reference calls random() (molecule, row, column over non-bonded candidate
+    pairs).  None draws them with torch.rand on the device (optionally from `generator`).
+    """
+    dev = dpacked.device
+    p = plan(dpacked.host, ids)
+    B, N, S, V, E, Ein, R = (p[k] for k in ('B', 'N', 'S', 'V', 'E', 'Ein', 'R'))
+    if N > 250:
+        raise ValueError(f'a molecule of {N} atoms exceeds PSVAE_MAX_ATOMS (250)')
+    offs = torch.from_numpy(p['offs']).to(dev, non_blocking=True)
+    node_off, edge_off, inedge_off, rng_off, mol_ids = offs[0], offs[1], offs[2], offs[3], offs[4]
+    if uniforms is None:
+        uniforms = torch.rand(max(R, 1), dtype=torch.float64, device=dev, generator=generator)
+    elif uniforms.numel() < R:
+        raise ValueError(f'{R} uniforms needed, {uniforms.numel()} given')
+    if uniforms.dtype != torch.float64 or not uniforms.is_cuda:
+        raise TypeError('uniforms must be a float64 device tensor')
+    pair_cnt = torch.empty(max(B, 1), dtype=torch.int32, device=dev)
+    pair_off = torch.empty(B + 1, dtype=torch.int32, device=dev)
+    hip.collate_count(B, N, mol_ids, dpacked, rng_off, uniforms, keep_prob, pair_cnt, pair_off)
+    P = int(pair_off[B].item())          # the one device->host read of collation
+
+    i32, i64, u8 = torch.int32, torch.int64, torch.uint8
+    ref, cmp_ = {}, {}
+    ref['pieces'] = torch.empty(B, S, dtype=i64, device=dev)
+    ref['props'] = torch.empty(B, 3, dtype=torch.float32, device=dev)
+    if reference_layout:
+        for k in ('x', 'x_pieces', 'x_pos'):
+            ref[k] = torch.empty(B, N, dtype=i64, device=dev)
+        ref['atom_mask'] = torch.empty(B, N, dtype=u8, device=dev)
+        ref['edge_index'] = torch.empty(2, E, dtype=i64, device=dev)
+        ref['edge_attr'] = torch.empty(E, num_bond_type, dtype=i64, device=dev)
+        ref['edge_select'] = torch.empty(B, N, N, dtype=u8, device=dev)
+        ref['golden_edge'] = torch.empty(P, dtype=i64, device=dev)
+        ref['in_piece_edge_idx'] = torch.empty(Ein, dtype=i64, device=dev)
+    if compact_layout:
+        for k in ('cx', 'cxp', 'cxpos'):
+            cmp_[k] = torch.empty(V, dtype=i32, device=dev)
+        cmp_['row_ptr'] = torch.empty(V + 1, dtype=i32, device=dev)
+        cmp_['col'] = torch.empty(E, dtype=i32, device=dev)
+        cmp_['cls'] = torch.empty(E, dtype=u8, device=dev)
+        cmp_['in_row_ptr'] = torch.empty(V + 1, dtype=i32, device=dev)
+        cmp_['in_col'] = torch.empty(Ein, dtype=i32, device=dev)
+        cmp_['in_cls'] = torch.empty(Ein, dtype=u8, device=dev)
+        for k in ('pair_src', 'pair_dst', 'pair_graph', 'golden32'):
+            cmp_[k] = torch.empty(P, dtype=i32, device=dev)
+        if B == 0 or V == 0:
+            cmp_['row_ptr'].zero_()
+            cmp_['in_row_ptr'].zero_()
+    hip.collate_fill(B, N, S, mol_ids, dpacked,
+                     {'node_off': node_off, 'edge_off': edge_off, 'inedge_off': inedge_off,
+                      'rng_off': rng_off, 'pair_off': pair_off},
+                     E, uniforms, keep_prob, atom_pad, piece_pad, num_bond_type, ref, cmp_)
+    out = CollatedBatch()
+    if reference_layout:
+        out.update(ref)
+        out['atom_mask'] = ref['atom_mask'].view(torch.bool)
+        out['edge_select'] = ref['edge_select'].view(torch.bool)
+    out.pieces, out.props, out.batch_size = ref['pieces'], ref['props'], B
+    out.num_uniforms = R
+    if compact_layout:
+        out.compact = CompactBatch(cmp_, node_off, pair_off, B)
+    return out

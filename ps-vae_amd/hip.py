@@ -1,0 +1,284 @@
+"""ctypes binding of csrc/libpsvae_hip.so (C ABI declared in include/psvae_hip.h).
+
+Thin by design: every wrapper checks that its tensors live on the GPU with the expected
+dtype / contiguity, passes raw device pointers plus PyTorch's current HIP stream, and turns
+a non-zero status into a RuntimeError carrying psvae_last_error().  There is no fallback:
+without the library, or with a CPU tensor, the call raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libpsvae_hip.so')
+
+_c_int, _c_i64, _c_size = ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
+_c_f32, _c_f64, _c_ll, _p = ctypes.c_float, ctypes.c_double, ctypes.c_longlong, ctypes.c_void_p
+
+# name -> (restype, argtypes); argument order follows include/psvae_hip.h
+_SIGNATURES = {
+    'psvae_version': (_c_int, []),
+    'psvae_last_error': (ctypes.c_char_p, []),
+    'psvae_collate_count': (_c_int, [_c_int, _c_int] + [_p] * 8 + [_p, _c_f64, _p, _p, _p]),
+    'psvae_collate_fill': (_c_int, [_c_int, _c_int, _c_int] + [_p] * 16 + [_c_ll, _p, _c_f64, _c_int, _c_int]
+                           + [_p] * 7 + [_c_int] + [_p] * 4 + [_p] * 13 + [_p]),
+    'psvae_exclusive_scan_i32': (_c_int, [_c_int, _p, _p, _p]),
+    'psvae_embed_atom_fwd': (_c_int, [_c_int, _p, _p, _p, _p, _c_int, _c_int, _p, _c_int, _c_int, _p, _c_int,
+                                      _c_int, _p, _p]),
+    'psvae_embed_atom_bwd': (_c_int, [_c_int, _p, _p, _p, _p] + [_c_int] * 6 + [_p, _p, _p, _p]),
+    'psvae_gine_aggregate_fwd': (_c_int, [_c_int, _c_int, _c_int, _p, _c_int, _p, _p, _p, _p, _p, _c_int, _p]),
+    'psvae_gine_aggregate_bwd_workspace_bytes': (_c_size, [_c_int, _c_int, _c_int]),
+    'psvae_gine_aggregate_bwd': (_c_int, [_c_int, _c_int, _c_int, _p, _c_int, _p, _p, _c_int, _p, _p, _p, _p,
+                                          _c_int, _p, _p, _c_size, _p]),
+    'psvae_gemm_f32_workspace_bytes': (_c_size, [_c_int, _c_int, _c_int, _c_int]),
+    'psvae_gemm_f32': (_c_int, [_c_int, _c_int, _c_int, _p, _p, _c_i64, _c_i64, _p, _c_i64, _c_i64, _p, _c_i64,
+                                _p, _c_int, _c_int, _c_int, _p, _c_size, _p]),
+    'psvae_colsum_workspace_bytes': (_c_size, [_c_int, _c_int]),
+    'psvae_colsum_f32': (_c_int, [_c_int, _c_int, _p, _p, _c_i64, _p, _c_int, _p, _c_size, _p]),
+    'psvae_segment_sum_fwd': (_c_int, [_c_int, _c_int, _p, _c_int, _p, _p, _p, _c_int, _p]),
+    'psvae_segment_sum_bwd': (_c_int, [_c_int, _c_int, _p, _c_int, _p, _p, _p, _c_int, _p]),
+    'psvae_rsample_kl_fwd': (_c_int, [_c_int, _c_int, _p, _p, _p, _p, _p, _p]),
+    'psvae_rsample_kl_bwd': (_c_int, [_c_int, _c_int, _p, _p, _p, _p, _p, _p, _p, _p]),
+    'psvae_pair_gather_fwd': (_c_int, [_c_int, _c_int, _c_int, _p, _c_int, _p, _c_int, _p, _p, _p, _p, _p]),
+    'psvae_pair_gather_bwd': (_c_int, [_c_int, _c_int, _c_int, _p, _p, _p, _p, _p, _p, _p, _c_int, _p, _c_int, _p]),
+    'psvae_link_ce_workspace_bytes': (_c_size, [_c_int]),
+    'psvae_link_ce_fwd': (_c_int, [_c_int, _c_int, _c_int, _p, _c_int, _p, _p, _p, _p, _p, _p, _p, _p, _c_size, _p]),
+    'psvae_link_ce_bwd_input': (_c_int, [_c_int, _c_int, _c_int, _p, _p, _p, _p, _c_int, _p]),
+    'psvae_link_infer': (_c_int, [_c_int, _c_int, _p, _c_f32, _c_int, _p, _p, _p, _p]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def lib():
+    """The loaded library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f'{LIB_PATH} is missing: build it with `make -C {os.path.dirname(LIB_PATH)}` '
+                               '(or __graft_entry__.build()); there is no CPU fallback')
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def _check(rc, name):
+    if rc != 0:
+        msg = lib().psvae_last_error().decode(errors='replace')
+        raise RuntimeError(f'{name} failed with status {rc}: {msg}')
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t, dtype=None):
+    """Device pointer of tensor t (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError('psvae HIP ops need GPU tensors (there is no CPU fallback)')
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f'expected {dtype}, got {t.dtype}')
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _rows(t):
+    """(pointer, row stride in elements) of a 2-D tensor whose last dim is contiguous."""
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise ValueError(f'need a 2-D tensor with contiguous rows, got shape {tuple(t.shape)} strides {t.stride()}')
+    return ptr(t, torch.float32), (t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1]))
+
+
+_workspaces = {}
+
+
+def workspace(nbytes, device):
+    """A per-device scratch buffer, grown on demand.  All users enqueue on PyTorch's current
+    stream, so successive kernels that reuse it are ordered."""
+    key = (device.type, device.index)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf
+
+
+# --------------------------------------------------------------------------- raw calls
+def gemm(M, N, K, A, sa_m, sa_k, B, sb_k, sb_n, C, ldc, bias=None, relu=False, accumulate=False,
+         amask=None, split_k=0):
+    L = lib()
+    nbytes = L.psvae_gemm_f32_workspace_bytes(M, N, K, split_k)
+    ws = workspace(nbytes, C.device) if nbytes else None
+    rc = L.psvae_gemm_f32(M, N, K, ptr(A, torch.float32), ptr(amask, torch.float32), sa_m, sa_k,
+                          ptr(B, torch.float32), sb_k, sb_n, ptr(C, torch.float32), ldc,
+                          ptr(bias, torch.float32), 1 if relu else 0, 1 if accumulate else 0, split_k,
+                          ptr(ws), nbytes, _stream())
+    _check(rc, 'psvae_gemm_f32')
+
+
+def colsum(x, out, mask=None, accumulate=False):
+    L = lib()
+    M, N = x.shape
+    px, ld = _rows(x)
+    if mask is not None and _rows(mask)[1] != ld:
+        raise ValueError('mask must have the row stride of x')
+    nbytes = L.psvae_colsum_workspace_bytes(M, N)
+    ws = workspace(nbytes, x.device) if nbytes else None
+    _check(L.psvae_colsum_f32(M, N, px, ptr(mask, torch.float32), ld, ptr(out, torch.float32),
+                              1 if accumulate else 0, ptr(ws), nbytes, _stream()), 'psvae_colsum_f32')
+
+
+def gine_aggregate_fwd(x, table, row_ptr, col, cls, out):
+    V, H = x.shape
+    px, ldx = _rows(x)
+    po, ldo = _rows(out)
+    _check(lib().psvae_gine_aggregate_fwd(V, H, table.shape[0], px, ldx, ptr(table, torch.float32),
+                                          ptr(row_ptr, torch.int32), ptr(col, torch.int32), ptr(cls, torch.uint8),
+                                          po, ldo, _stream()), 'psvae_gine_aggregate_fwd')
+
+
+def gine_aggregate_bwd(x, table, g, t_row_ptr, t_col, t_cls, g_x, g_table):
+    L = lib()
+    V, H = x.shape
+    C = table.shape[0]
+    px, ldx = _rows(x)
+    pg, ldg = _rows(g)
+    pgx, ldgx = _rows(g_x)
+    nbytes = L.psvae_gine_aggregate_bwd_workspace_bytes(V, H, C)
+    ws = workspace(nbytes, x.device) if nbytes else None
+    _check(L.psvae_gine_aggregate_bwd(V, H, C, px, ldx, ptr(table, torch.float32), pg, ldg,
+                                      ptr(t_row_ptr, torch.int32), ptr(t_col, torch.int32), ptr(t_cls, torch.uint8),
+                                      pgx, ldgx, ptr(g_table, torch.float32), ptr(ws), nbytes, _stream()),
+           'psvae_gine_aggregate_bwd')
+
+
+def embed_atom_fwd(x, xp, xq, ea, ep, eq, out):
+    _check(lib().psvae_embed_atom_fwd(x.numel(), ptr(x, torch.int32), ptr(xp, torch.int32), ptr(xq, torch.int32),
+                                      ptr(ea, torch.float32), ea.shape[0], ea.shape[1],
+                                      ptr(ep, torch.float32), ep.shape[0], ep.shape[1],
+                                      ptr(eq, torch.float32), eq.shape[0], eq.shape[1],
+                                      ptr(out, torch.float32), _stream()), 'psvae_embed_atom_fwd')
+
+
+def embed_atom_bwd(x, xp, xq, g, ga, gp, gq):
+    _check(lib().psvae_embed_atom_bwd(x.numel(), ptr(x, torch.int32), ptr(xp, torch.int32), ptr(xq, torch.int32),
+                                      ptr(g, torch.float32), ga.shape[0], ga.shape[1], gp.shape[0], gp.shape[1],
+                                      gq.shape[0], gq.shape[1], ptr(ga, torch.float32), ptr(gp, torch.float32),
+                                      ptr(gq, torch.float32), _stream()), 'psvae_embed_atom_bwd')
+
+
+def segment_sum_fwd(x, seg_begin, seg_end, out):
+    px, ldx = _rows(x)
+    po, ldo = _rows(out)
+    _check(lib().psvae_segment_sum_fwd(out.shape[0], x.shape[1], px, ldx, ptr(seg_begin, torch.int32),
+                                       ptr(seg_end, torch.int32), po, ldo, _stream()), 'psvae_segment_sum_fwd')
+
+
+def segment_sum_bwd(g_out, seg_begin, seg_end, g_x):
+    pg, ldg = _rows(g_out)
+    px, ldx = _rows(g_x)
+    _check(lib().psvae_segment_sum_bwd(g_out.shape[0], g_out.shape[1], pg, ldg, ptr(seg_begin, torch.int32),
+                                       ptr(seg_end, torch.int32), px, ldx, _stream()), 'psvae_segment_sum_bwd')
+
+
+def rsample_kl_fwd(mean, lv_pre, eps, z, kl):
+    B, Ld = mean.shape
+    _check(lib().psvae_rsample_kl_fwd(B, Ld, ptr(mean, torch.float32), ptr(lv_pre, torch.float32),
+                                      ptr(eps, torch.float32), ptr(z, torch.float32), ptr(kl, torch.float32),
+                                      _stream()), 'psvae_rsample_kl_fwd')
+
+
+def rsample_kl_bwd(mean, lv_pre, eps, g_z, g_kl, g_mean, g_lv_pre):
+    B, Ld = mean.shape
+    _check(lib().psvae_rsample_kl_bwd(B, Ld, ptr(mean, torch.float32), ptr(lv_pre, torch.float32),
+                                      ptr(eps, torch.float32), ptr(g_z, torch.float32), ptr(g_kl, torch.float32),
+                                      ptr(g_mean, torch.float32), ptr(g_lv_pre, torch.float32), _stream()),
+           'psvae_rsample_kl_bwd')
+
+
+def pair_gather_fwd(h, z, src, dst, graph, feats):
+    ph, ldh = _rows(h)
+    pz, ldz = _rows(z)
+    _check(lib().psvae_pair_gather_fwd(src.numel(), h.shape[1], z.shape[1], ph, ldh, pz, ldz,
+                                       ptr(src, torch.int32), ptr(dst, torch.int32), ptr(graph, torch.int32),
+                                       ptr(feats, torch.float32), _stream()), 'psvae_pair_gather_fwd')
+
+
+def pair_gather_bwd(g_feats, src, dst, pair_ptr, node_begin, node_end, g_h, g_z):
+    pgh, ldgh = _rows(g_h)
+    pgz, ldgz = _rows(g_z)
+    _check(lib().psvae_pair_gather_bwd(g_z.shape[0], g_h.shape[1], g_z.shape[1], ptr(g_feats, torch.float32),
+                                       ptr(src, torch.int32), ptr(dst, torch.int32), ptr(pair_ptr, torch.int32),
+                                       ptr(node_begin, torch.int32), ptr(node_end, torch.int32), pgh, ldgh,
+                                       pgz, ldgz, _stream()), 'psvae_pair_gather_bwd')
+
+
+def link_ce_fwd(hid, W, b, golden, logits, dlogits, loss, n_correct):
+    L = lib()
+    P, F = hid.shape
+    ph, ldh = _rows(hid) if P else (None, F)
+    nbytes = L.psvae_link_ce_workspace_bytes(P)
+    ws = workspace(nbytes, W.device)
+    _check(L.psvae_link_ce_fwd(P, F, W.shape[0], ph, ldh, ptr(W, torch.float32), ptr(b, torch.float32),
+                               ptr(golden, torch.int32), ptr(logits, torch.float32), ptr(dlogits, torch.float32),
+                               ptr(loss, torch.float32), ptr(n_correct, torch.int32), ptr(ws), nbytes, _stream()),
+           'psvae_link_ce_fwd')
+
+
+def link_ce_bwd_input(dlogits, W, g_loss, g_hid):
+    P, C = dlogits.shape
+    pg, ldg = _rows(g_hid) if P else (None, W.shape[1])
+    _check(lib().psvae_link_ce_bwd_input(P, W.shape[1], C, ptr(dlogits, torch.float32), ptr(W, torch.float32),
+                                         ptr(g_loss, torch.float32), pg, ldg, _stream()), 'psvae_link_ce_bwd_input')
+
+
+def link_infer(logits, add_edge_th, none_bond, conf, etype, keep):
+    P, C = logits.shape
+    _check(lib().psvae_link_infer(P, C, ptr(logits, torch.float32), float(add_edge_th), int(none_bond),
+                                  ptr(conf, torch.float32), ptr(etype, torch.int32), ptr(keep, torch.uint8),
+                                  _stream()), 'psvae_link_infer')
+
+
+def exclusive_scan(inp, out):
+    _check(lib().psvae_exclusive_scan_i32(inp.numel(), ptr(inp, torch.int32), ptr(out, torch.int32), _stream()),
+           'psvae_exclusive_scan_i32')
+
+
+def collate_count(B, N, mol_ids, packed, rng_off, uniforms, keep_prob, pair_cnt, pair_off):
+    _check(lib().psvae_collate_count(B, N, ptr(mol_ids, torch.int32), ptr(packed.atom_off), ptr(packed.atom_pos),
+                                     ptr(packed.bond_off), ptr(packed.bond_a), ptr(packed.bond_b),
+                                     ptr(packed.bond_cls), ptr(rng_off, torch.int32), ptr(uniforms, torch.float64),
+                                     float(keep_prob), ptr(pair_cnt, torch.int32), ptr(pair_off, torch.int32),
+                                     _stream()), 'psvae_collate_count')
+
+
+def collate_fill(B, N, S, mol_ids, packed, offs, E, uniforms, keep_prob, atom_pad, piece_pad, num_bond_type,
+                 ref, compact):
+    """offs: dict node_off/edge_off/inedge_off/rng_off/pair_off; ref / compact: dicts of output
+    tensors (missing key -> NULL -> that tensor is not written)."""
+    r = lambda k, dt: ptr(ref.get(k), dt)          # noqa: E731
+    c = lambda k, dt: ptr(compact.get(k), dt)      # noqa: E731
+    i32, i64, u8, f32 = torch.int32, torch.int64, torch.uint8, torch.float32
+    rc = lib().psvae_collate_fill(
+        B, N, S, ptr(mol_ids, i32), ptr(packed.atom_off), ptr(packed.atom_type), ptr(packed.atom_pos),
+        ptr(packed.bond_off), ptr(packed.bond_a), ptr(packed.bond_b), ptr(packed.bond_cls),
+        ptr(packed.piece_off), ptr(packed.piece_id), ptr(packed.props, f32),
+        ptr(offs['node_off'], i32), ptr(offs['edge_off'], i32), ptr(offs['inedge_off'], i32),
+        ptr(offs['rng_off'], i32), ptr(offs['pair_off'], i32), int(E), ptr(uniforms, torch.float64),
+        float(keep_prob), int(atom_pad), int(piece_pad),
+        r('x', i64), r('x_pieces', i64), r('x_pos', i64), r('atom_mask', u8), r('pieces', i64),
+        r('edge_index', i64), r('edge_attr', i64), int(num_bond_type), r('edge_select', u8),
+        r('golden_edge', i64), r('in_piece_edge_idx', i64), r('props', f32),
+        c('cx', i32), c('cxp', i32), c('cxpos', i32), c('row_ptr', i32), c('col', i32), c('cls', u8),
+        c('in_row_ptr', i32), c('in_col', i32), c('in_cls', u8),
+        c('pair_src', i32), c('pair_dst', i32), c('pair_graph', i32), c('golden32', i32), _stream())
+    _check(rc, 'psvae_collate_fill')

@@ -1,0 +1,137 @@
+"""VAE piece decoder with the reference's constructor, methods and state_dict keys
+(src/modules/vae_piece_decoder.py:16-126, and the link-prediction slice of inference,
+:203-241).
+
+What runs where: embeddings, the second GINE pass, the pair gather, the link MLP, the link
+loss and the reparameterised latent are HIP kernels (ps_vae_amd.ops); the teacher-forced
+GRU piece language model (:81-90) is PyTorch's stock GRU on the GPU.  The RDKit-based
+molecule assembly of `inference` (:160-201, 243-274) is outside the hot path."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import hip, ops
+from .common_nn import MLP, run_linear
+from .encoder import Encoder
+
+
+class VAEPieceDecoder(nn.Module):
+    def __init__(self, atom_embedding_dim, piece_embedding_dim, max_pos, pos_embedding_dim, piece_hidden_dim,
+                 node_hidden_dim, num_edge_type, cond_dim, latent_dim, tokenizer, t=4):
+        super(VAEPieceDecoder, self).__init__()
+        self.tokenizer = tokenizer
+        self.atom_embedding = nn.Embedding(tokenizer.num_atom_type(), atom_embedding_dim)
+        self.piece_embedding = nn.Embedding(tokenizer.num_piece_type(), piece_embedding_dim)
+        self.pos_embedding = nn.Embedding(max_pos, pos_embedding_dim)
+        self.latent_to_rnn_hidden = nn.Linear(latent_dim, piece_hidden_dim)
+        self.rnn = nn.GRU(piece_embedding_dim, piece_hidden_dim, batch_first=True)
+        self.to_vocab = nn.Linear(piece_hidden_dim, tokenizer.num_piece_type())
+        node_dim = atom_embedding_dim + piece_embedding_dim + pos_embedding_dim
+        self.graph_embedding = Encoder(node_dim, num_edge_type, node_hidden_dim, dim_out=1, t=t)
+        mlp_in = node_hidden_dim * 2 + latent_dim
+        self.edge_predictor = nn.Sequential(
+            MLP(dim_in=mlp_in, dim_hidden=mlp_in // 2, dim_out=mlp_in, act_func=nn.ReLU, num_layers=3),
+            nn.Linear(mlp_in, num_edge_type))
+        self.latent_dim = latent_dim
+        self.W_mean = nn.Linear(cond_dim, latent_dim)
+        self.W_log_var = nn.Linear(cond_dim, latent_dim)
+        self.piece_loss = nn.CrossEntropyLoss(ignore_index=tokenizer.pad_idx())
+        self.edge_loss = nn.CrossEntropyLoss()   # kept for API parity; the fused kernel computes it
+
+    def rsample(self, conds, eps=None):
+        """:56-63.  `eps` injects the normal draw (the reference calls torch.randn_like)."""
+        z_mean = run_linear(self.W_mean, conds)
+        z_log_var_pre = run_linear(self.W_log_var, conds)
+        if eps is None:
+            eps = torch.randn_like(z_mean)
+        return ops.rsample_kl(z_mean, z_log_var_pre, eps)
+
+    def embed_atom(self, atom_ids, piece_ids, pos_ids):
+        """:65-69 — ids of any shape -> [..., atom+piece+pos dims]."""
+        shape = atom_ids.shape
+        flat = [t.reshape(-1).to(torch.int32) for t in (atom_ids, piece_ids, pos_ids)]
+        out = ops.embed_atom(flat[0], flat[1], flat[2], self.atom_embedding.weight,
+                             self.piece_embedding.weight, self.pos_embedding.weight)
+        return out.view(*shape, out.shape[-1])
+
+    def piece_logits(self, z_vecs, pieces):
+        """:81-90 — teacher-forced GRU over the piece sequence, initial state from z."""
+        emb = self.piece_embedding(pieces)
+        init_hidden = run_linear(self.latent_to_rnn_hidden, z_vecs).unsqueeze(0)
+        output, _ = self.rnn(emb[:, :-1], init_hidden)
+        return run_linear(self.to_vocab, output)
+
+    def link_logits(self, node_embedding, z_vecs, pairs, golden=None):
+        """:99-110 (+ :115 when `golden` is given).  node_embedding [V,H] in the node ids the
+        pair list uses.  Returns (logits, loss or None, n_correct or None)."""
+        feats = ops.pair_gather(node_embedding, z_vecs, pairs)
+        hid = self.edge_predictor[0](feats)
+        last = self.edge_predictor[1]
+        if golden is None:
+            return run_linear(last, hid), None, None
+        loss, logits, n_ok = ops.link_ce(hid, last.weight, last.bias, golden)
+        return logits, loss, n_ok
+
+    def forward(self, x, x_pieces, x_pos, edge_index, edge_attr, pieces, conds, edge_select, golden_edge,
+                return_accu=False, eps=None):
+        """:71-126.  Accepts the reference's tensors (x [B,N,D], edge_index/edge_attr of the
+        in-piece edges, edge_select [B,N,N] bool, golden_edge [P] int64) or the compact
+        containers (x [V,D], edge_index = ops.Csr, edge_select = ops.PairList)."""
+        z_vecs, kl_loss = self.rsample(conds, eps)
+        gold_piece = pieces[:, 1:].flatten()
+        output = self.piece_logits(z_vecs, pieces)
+
+        node_dim = x.shape[-1]
+        node_x = x.reshape(-1, node_dim)
+        node_embedding, _ = self.graph_embedding.embed_node(node_x, edge_index, edge_attr)
+        pairs = edge_select if isinstance(edge_select, ops.PairList) else ops.PairList.from_edge_select(edge_select)
+        golden = golden_edge if golden_edge.dtype == torch.int32 else golden_edge.to(torch.int32)
+        pred_edge, edge_loss, n_ok = self.link_logits(node_embedding, z_vecs, pairs, golden)
+
+        pred_piece = output.reshape(-1, output.shape[-1])
+        piece_loss = self.piece_loss(pred_piece, gold_piece)
+        rec_loss = piece_loss + edge_loss
+        loss_tuple = (rec_loss, piece_loss, edge_loss, kl_loss)
+        if return_accu:
+            not_pad = (gold_piece != self.tokenizer.pad_idx())
+            piece_accu = ((torch.argmax(pred_piece, dim=-1) == gold_piece) & not_pad).sum().item() / not_pad.sum().item()
+            edge_accu = n_ok.item() / len(golden)
+            return z_vecs, (loss_tuple, (piece_accu, edge_accu))
+        return z_vecs, loss_tuple
+
+    @torch.no_grad()
+    def infer_links(self, z, x, x_pieces, x_pos, edge_index, edge_attr, groups, add_edge_th):
+        """Link prediction over ALL candidate pairs of generated fragments (:203-241):
+        candidates = upper triangle minus pairs inside one fragment, softmax, (max prob,
+        argmax), keep conf >= add_edge_th and type != None, order by confidence descending
+        (stable).  `groups`: list of atom-id lists, one per fragment.
+        Returns (pairs [Ec,2] int64, confidence [Ec], edge_type [Ec] int64, sorted_idx list)."""
+        dev = self.W_mean.weight.device
+        n = x.numel()
+        node_x = self.embed_atom(x.to(dev), x_pieces.to(dev), x_pos.to(dev))
+        h, _ = self.graph_embedding.embed_node(node_x, edge_index.to(dev), edge_attr.to(dev))
+        frag = torch.full((n,), -1, dtype=torch.int64)
+        for gi, g in enumerate(groups):
+            frag[torch.as_tensor(g, dtype=torch.int64)] = gi
+        frag = frag.to(dev)
+        sel = torch.triu(torch.ones(n, n, dtype=torch.bool, device=dev))
+        sel &= ~((frag[:, None] == frag[None, :]) & (frag[:, None] >= 0))
+        pairs = ops.PairList.from_edge_select(sel.unsqueeze(0))
+        idx = torch.stack([pairs.src, pairs.dst], dim=1).to(torch.int64)
+        if len(pairs) == 0:
+            return idx, torch.zeros(0, device=dev), torch.zeros(0, dtype=torch.int64, device=dev), []
+        logits, _, _ = self.link_logits(h, z.to(dev).view(1, -1), pairs)
+        P = logits.shape[0]
+        conf = torch.empty(P, dtype=torch.float32, device=dev)
+        etype = torch.empty(P, dtype=torch.int32, device=dev)
+        keep = torch.empty(P, dtype=torch.uint8, device=dev)
+        hip.link_infer(logits.contiguous(), add_edge_th, self.tokenizer.chem_vocab.bond_to_idx(None), conf, etype, keep)
+        kept = keep.bool().nonzero().flatten()
+        order = kept[torch.argsort(conf[kept], descending=True, stable=True)]
+        return idx, conf, etype.to(torch.int64), order.tolist()
+
+    def inference(self, z, max_atom_num, add_edge_th, temperature):
+        raise NotImplementedError(
+            'molecule assembly needs RDKit (piece SMILES -> atoms, valence / cycle checks, sanitisation: '
+            'src/modules/vae_piece_decoder.py:160-201, 243-274) and is outside the accelerated path; '
+            'its link-prediction slice is VAEPieceDecoder.infer_links')

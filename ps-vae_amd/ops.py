@@ -1,0 +1,323 @@
+"""Differentiable operators of the hot path: torch.autograd.Function wrappers whose forward
+and backward are calls into the HIP library (ps_vae_amd.hip).  PyTorch only owns the tensors,
+the autograd graph and the stream."""
+import torch
+from torch.autograd import Function
+
+from . import hip
+
+
+# ------------------------------------------------------------------------ index containers
+class Csr:
+    """Adjacency for message passing.  (row_ptr, col, cls) is the CSR over DESTINATION nodes
+    (col = source of each incoming edge, in edge order); (t_row_ptr, t_col, t_cls) the CSR
+    over SOURCE nodes, used by the backward pass.  For a symmetric graph whose edge list is
+    sorted by source — what collation produces — the two coincide."""
+
+    def __init__(self, row_ptr, col, cls, t_row_ptr=None, t_col=None, t_cls=None):
+        self.row_ptr, self.col, self.cls = row_ptr, col, cls
+        self.t_row_ptr = row_ptr if t_row_ptr is None else t_row_ptr
+        self.t_col = col if t_col is None else t_col
+        self.t_cls = cls if t_cls is None else t_cls
+
+    @property
+    def num_nodes(self):
+        return self.row_ptr.numel() - 1
+
+    @classmethod
+    def from_edge_index(cls, edge_index, edge_attr, num_nodes):
+        """From the reference's tensors: edge_index [2,E] int64 (row 0 = source, row 1 =
+        destination, src/modules/encoder.py:58) and one-hot edge_attr [E,C].  Index
+        bookkeeping only (stable sorts keep the edge order inside every row)."""
+        src, dst = edge_index[0], edge_index[1]
+        if edge_attr.dim() == 2:
+            klass = edge_attr.argmax(dim=1)
+        else:
+            klass = edge_attr
+        klass = klass.to(torch.uint8)
+
+        def build(key, other):
+            order = torch.argsort(key, stable=True)
+            counts = torch.bincount(key, minlength=num_nodes)
+            ptr = torch.zeros(num_nodes + 1, dtype=torch.int32, device=key.device)
+            ptr[1:] = torch.cumsum(counts, 0)
+            return ptr, other[order].to(torch.int32).contiguous(), klass[order].contiguous()
+
+        row_ptr, col, c = build(dst, src)
+        t_row_ptr, t_col, t_c = build(src, dst)
+        return cls(row_ptr, col, c, t_row_ptr, t_col, t_c)
+
+
+class Segments:
+    """Row ranges [begin[b], end[b]) of the graphs of a batch inside a node-major matrix."""
+
+    def __init__(self, begin, end, covers_all_rows):
+        self.begin, self.end, self.covers_all_rows = begin, end, covers_all_rows
+
+    @property
+    def num_graphs(self):
+        return self.begin.numel()
+
+    @classmethod
+    def from_offsets(cls, node_off):
+        return cls(node_off[:-1], node_off[1:], True)
+
+
+class PairList:
+    """Candidate atom pairs in row-major (graph, m, n) order: node ids src/dst, graph id,
+    ptr [B+1] (pairs of graph b are ptr[b]..ptr[b+1]) and the node range of every graph."""
+
+    def __init__(self, src, dst, graph, ptr, nodes):
+        self.src, self.dst, self.graph, self.ptr, self.nodes = src, dst, graph, ptr, nodes
+
+    def __len__(self):
+        return self.src.numel()
+
+    @classmethod
+    def from_edge_select(cls, edge_select):
+        """edge_select [B,N,N] bool over PADDED node ids b*N + m
+        (src/modules/vae_piece_decoder.py:99-109)."""
+        B, N, _ = edge_select.shape
+        b, m, n = edge_select.nonzero(as_tuple=True)
+        dev = edge_select.device
+        ptr = torch.zeros(B + 1, dtype=torch.int32, device=dev)
+        ptr[1:] = torch.cumsum(torch.bincount(b, minlength=B), 0)
+        begin = (torch.arange(B, device=dev, dtype=torch.int32) * N)
+        nodes = Segments(begin, begin + N, True)
+        return cls((b * N + m).to(torch.int32), (b * N + n).to(torch.int32), b.to(torch.int32), ptr, nodes)
+
+
+def _rows2d(t):
+    """2-D float32 view with contiguous rows (copying only if the last dim is strided)."""
+    if t.dim() != 2:
+        t = t.reshape(-1, t.shape[-1])
+    if t.dtype != torch.float32:
+        t = t.float()
+    if t.shape[1] > 1 and t.stride(1) != 1:
+        t = t.contiguous()
+    if t.shape[0] > 1 and t.stride(0) < t.shape[1]:   # expanded rows
+        t = t.contiguous()
+    return t
+
+
+def _ld(t):
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+# ------------------------------------------------------------------------ Linear
+class _Linear(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        x2 = _rows2d(x)
+        M, K = x2.shape
+        N = weight.shape[0]
+        w = weight if weight.stride(1) == 1 else weight.contiguous()
+        out = torch.empty(M, N, dtype=torch.float32, device=x2.device)
+        hip.gemm(M, N, K, x2, _ld(x2), 1, w, 1, w.stride(0), out, N, bias=bias, relu=relu)
+        ctx.relu = relu
+        ctx.has_bias = bias is not None
+        ctx.lead = x.shape[:-1]
+        ctx.save_for_backward(x2, w, out if relu else None)
+        return out.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, w, out = ctx.saved_tensors
+        M, K = x2.shape
+        N = w.shape[0]
+        g2 = g.reshape(M, N)
+        if g2.dtype != torch.float32 or not g2.is_contiguous():
+            g2 = g2.float().contiguous()
+        mask = out if ctx.relu else None
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty(M, K, dtype=torch.float32, device=g2.device)
+            hip.gemm(M, K, N, g2, N, 1, w, w.stride(0), 1, gx, K, amask=mask)
+            gx = gx.view(*ctx.lead, K)
+        if ctx.needs_input_grad[1]:
+            gw = torch.empty(N, K, dtype=torch.float32, device=g2.device)
+            hip.gemm(N, K, M, g2, 1, N, x2, _ld(x2), 1, gw, K, amask=mask, split_k=0)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = torch.empty(N, dtype=torch.float32, device=g2.device)
+            hip.colsum(g2, gb, mask=mask)
+        return gx, gw, gb, None
+
+
+def linear(x, weight, bias=None, relu=False):
+    """act(x W^T + b) — nn.Linear (+ ReLU) on the MFMA GEMM (src/modules/common_nn.py:15-20)."""
+    return _Linear.apply(x, weight, bias, relu)
+
+
+# ------------------------------------------------------------------------ GINE aggregate
+class _GineAggregate(Function):
+    @staticmethod
+    def forward(ctx, x, table, csr):
+        x2 = _rows2d(x)
+        table = table.contiguous()
+        out = torch.empty(x2.shape[0], x2.shape[1], dtype=torch.float32, device=x2.device)
+        hip.gine_aggregate_fwd(x2, table, csr.row_ptr, csr.col, csr.cls, out)
+        ctx.csr = csr
+        ctx.save_for_backward(x2, table)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, table = ctx.saved_tensors
+        g2 = g if (g.dtype == torch.float32 and g.is_contiguous()) else g.float().contiguous()
+        gx = torch.empty_like(g2)
+        gt = torch.empty_like(table)
+        csr = ctx.csr
+        hip.gine_aggregate_bwd(x2, table, g2, csr.t_row_ptr, csr.t_col, csr.t_cls, gx, gt)
+        return gx, gt, None
+
+
+def gine_aggregate(x, table, csr):
+    """x + sum over incoming edges of ReLU(x[source] + table[bond class])."""
+    return _GineAggregate.apply(x, table, csr)
+
+
+# ------------------------------------------------------------------------ embed_atom
+class _EmbedAtom(Function):
+    @staticmethod
+    def forward(ctx, x, xp, xq, ea, ep, eq):
+        ea, ep, eq = ea.contiguous(), ep.contiguous(), eq.contiguous()
+        out = torch.empty(x.numel(), ea.shape[1] + ep.shape[1] + eq.shape[1], dtype=torch.float32, device=ea.device)
+        hip.embed_atom_fwd(x, xp, xq, ea, ep, eq, out)
+        ctx.save_for_backward(x, xp, xq)
+        ctx.shapes = (ea.shape, ep.shape, eq.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, xp, xq = ctx.saved_tensors
+        g2 = g if (g.dtype == torch.float32 and g.is_contiguous()) else g.float().contiguous()
+        ga, gp, gq = (torch.zeros(s, dtype=torch.float32, device=g2.device) for s in ctx.shapes)
+        hip.embed_atom_bwd(x, xp, xq, g2, ga, gp, gq)
+        return None, None, None, ga, gp, gq
+
+
+def embed_atom(x, xp, xq, e_atom, e_piece, e_pos):
+    """[E_atom[x] | E_piece[xp] | E_pos[xq]] for flat int32 id vectors -> [V, D]."""
+    return _EmbedAtom.apply(x, xp, xq, e_atom, e_piece, e_pos)
+
+
+# ------------------------------------------------------------------------ segment sum
+class _SegmentSum(Function):
+    @staticmethod
+    def forward(ctx, x, segs):
+        x2 = _rows2d(x)
+        out = torch.empty(segs.num_graphs, x2.shape[1], dtype=torch.float32, device=x2.device)
+        hip.segment_sum_fwd(x2, segs.begin, segs.end, out)
+        ctx.segs, ctx.rows = segs, x2.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g2 = g if (g.dtype == torch.float32 and g.is_contiguous()) else g.float().contiguous()
+        alloc = torch.empty if ctx.segs.covers_all_rows else torch.zeros
+        gx = alloc(ctx.rows, g2.shape[1], dtype=torch.float32, device=g2.device)
+        hip.segment_sum_bwd(g2, ctx.segs.begin, ctx.segs.end, gx)
+        return gx, None
+
+
+def segment_sum(x, segs):
+    return _SegmentSum.apply(x, segs)
+
+
+# ------------------------------------------------------------------------ rsample + KL
+class _RsampleKl(Function):
+    @staticmethod
+    def forward(ctx, mean, lv_pre, eps):
+        mean, lv_pre, eps = mean.contiguous(), lv_pre.contiguous(), eps.contiguous()
+        z = torch.empty_like(mean)
+        kl = torch.empty((), dtype=torch.float32, device=mean.device)
+        hip.rsample_kl_fwd(mean, lv_pre, eps, z, kl)
+        ctx.save_for_backward(mean, lv_pre, eps)
+        return z, kl
+
+    @staticmethod
+    def backward(ctx, g_z, g_kl):
+        mean, lv_pre, eps = ctx.saved_tensors
+        g_z = None if g_z is None else g_z.contiguous()
+        g_kl = None if g_kl is None else g_kl.contiguous()
+        g_mean, g_lv = torch.empty_like(mean), torch.empty_like(mean)
+        hip.rsample_kl_bwd(mean, lv_pre, eps, g_z, g_kl, g_mean, g_lv)
+        return g_mean, g_lv, None
+
+
+def rsample_kl(mean, lv_pre, eps):
+    return _RsampleKl.apply(mean, lv_pre, eps)
+
+
+# ------------------------------------------------------------------------ pair features
+class _PairGather(Function):
+    @staticmethod
+    def forward(ctx, h, z, pairs):
+        h2, z2 = _rows2d(h), _rows2d(z)
+        feats = torch.empty(len(pairs), 2 * h2.shape[1] + z2.shape[1], dtype=torch.float32, device=h2.device)
+        hip.pair_gather_fwd(h2, z2, pairs.src, pairs.dst, pairs.graph, feats)
+        ctx.pairs, ctx.hshape, ctx.zshape = pairs, h2.shape, z2.shape
+        return feats
+
+    @staticmethod
+    def backward(ctx, g):
+        pairs = ctx.pairs
+        g2 = g if (g.dtype == torch.float32 and g.is_contiguous()) else g.float().contiguous()
+        alloc = torch.empty if pairs.nodes.covers_all_rows else torch.zeros
+        g_h = alloc(ctx.hshape, dtype=torch.float32, device=g2.device)
+        g_z = torch.empty(ctx.zshape, dtype=torch.float32, device=g2.device)
+        hip.pair_gather_bwd(g2 if len(pairs) else None, pairs.src, pairs.dst, pairs.ptr, pairs.nodes.begin,
+                            pairs.nodes.end, g_h, g_z)
+        return g_h, g_z, None
+
+
+def pair_gather(h, z, pairs):
+    """[h[src] | h[dst] | z[graph]] per candidate pair."""
+    return _PairGather.apply(h, z, pairs)
+
+
+# ------------------------------------------------------------------------ link loss
+class _LinkCe(Function):
+    @staticmethod
+    def forward(ctx, hid, weight, bias, golden):
+        hid2 = _rows2d(hid)
+        w = weight.contiguous()
+        P, C = hid2.shape[0], w.shape[0]
+        dev = w.device
+        logits = torch.empty(P, C, dtype=torch.float32, device=dev)
+        dlogits = torch.empty(P, C, dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        n_correct = torch.empty((), dtype=torch.int32, device=dev)
+        hip.link_ce_fwd(hid2, w, bias, golden, logits, dlogits, loss, n_correct)
+        ctx.save_for_backward(hid2, w, dlogits)
+        ctx.has_bias = bias is not None
+        ctx.mark_non_differentiable(logits, n_correct)
+        return loss, logits, n_correct
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_logits, _g_ok):
+        hid2, w, dlogits = ctx.saved_tensors
+        P, F = hid2.shape
+        C = w.shape[0]
+        g_loss = g_loss.contiguous().float()
+        g_hid = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            g_hid = torch.empty(P, F, dtype=torch.float32, device=w.device)
+            hip.link_ce_bwd_input(dlogits, w, g_loss, g_hid)
+        if ctx.needs_input_grad[1]:
+            gw = torch.zeros(C, F, dtype=torch.float32, device=w.device)
+            if P:
+                hip.gemm(C, F, P, dlogits, 1, C, hid2, _ld(hid2), 1, gw, F, split_k=0)
+            gw = gw * g_loss
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = torch.zeros(C, dtype=torch.float32, device=w.device)
+            if P:
+                hip.colsum(dlogits, gb)
+            gb = gb * g_loss
+        return g_hid, gw, gb, None
+
+
+def link_ce(hid, weight, bias, golden):
+    """Last Linear of the link predictor + mean 4-class cross-entropy.
+    Returns (loss, logits [P,C], n_correct)."""
+    return _LinkCe.apply(hid, weight, bias, golden)

@@ -1,0 +1,1 @@
+from .ps_vae_model import PSVAEModel  # noqa: F401

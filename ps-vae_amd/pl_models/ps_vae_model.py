@@ -1,0 +1,187 @@
+"""PSVAEModel with the reference's interface (src/pl_models/ps_vae_model.py:18-193).
+
+pytorch_lightning is not part of this stack, so the class derives from nn.Module and keeps
+the hook methods a Lightning Trainer (or ps_vae_amd.train.fit) calls: training_step,
+validation_step, test_step, configure_optimizers, plus global_step / log.
+
+forward() takes either the reference's batch dict (any source) or a CollatedBatch whose
+`.compact` layout is present; in the second case no index preparation happens on the way:
+the kernels read the CSR / pair lists collation wrote."""
+import time
+
+import torch
+import torch.nn as nn
+
+from ..data.bpe_dataset import BPEMolDataset, get_dataloader
+from ..modules.encoder import Encoder
+from ..modules.predictor import Predictor
+from ..modules.vae_piece_decoder import VAEPieceDecoder
+
+PROPS = ['qed', 'sa', 'logp']   # src/evaluation/utils.py:122
+
+
+class PSVAEModel(nn.Module):
+    def __init__(self, config, tokenizer):
+        super(PSVAEModel, self).__init__()
+        self.config = config
+        self.tokenizer = tokenizer
+        self.chem_vocab = tokenizer.chem_vocab
+        self.predictor = Predictor(**(config['predictor']))
+        self.encoder = Encoder(**(config['encoder']))
+        self.decoder = VAEPieceDecoder(**(config['vae_piece_decoder']))
+        self.pred_loss = nn.MSELoss()
+        self.total_time = 0
+        self.global_step = 0
+        self.logged = {}
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    def log(self, name, value, **kwargs):
+        self.logged[name] = value
+
+    def forward(self, batch, return_accu=False, eps=None):
+        compact = getattr(batch, 'compact', None)
+        if compact is not None:
+            x = self.decoder.embed_atom(compact.cx, compact.cxp, compact.cxpos)          # [V, D]
+            _, all_x = self.encoder.embed_node(x, compact.csr)
+            graph_embedding = self.encoder.embed_graph(all_x, compact.segments)
+            batch_size = compact.num_graphs
+            z, res = self.decoder(x=x, x_pieces=None, x_pos=None, edge_index=compact.csr_in, edge_attr=None,
+                                  pieces=batch.pieces, conds=graph_embedding, edge_select=compact.pairs,
+                                  golden_edge=compact.golden, return_accu=return_accu, eps=eps)
+            props = batch.props
+        else:
+            x, edge_index, edge_attr = batch['x'], batch['edge_index'], batch['edge_attr']
+            x_pieces, x_pos = batch['x_pieces'], batch['x_pos']
+            x = self.decoder.embed_atom(x, x_pieces, x_pos)
+            batch_size, node_num, node_dim = x.shape
+            graph_ids = torch.repeat_interleave(torch.arange(0, batch_size, device=x.device), node_num)
+            _, all_x = self.encoder.embed_node(x.view(-1, node_dim), edge_index, edge_attr)
+            graph_embedding = self.encoder.embed_graph(all_x, graph_ids, batch['atom_mask'].flatten())
+            in_piece_edge_idx = batch['in_piece_edge_idx']
+            if not torch.is_tensor(in_piece_edge_idx):
+                in_piece_edge_idx = torch.tensor(in_piece_edge_idx, dtype=torch.long, device=x.device)
+            z, res = self.decoder(x=x, x_pieces=x_pieces, x_pos=x_pos,
+                                  edge_index=edge_index[:, in_piece_edge_idx],
+                                  edge_attr=edge_attr[in_piece_edge_idx],
+                                  pieces=batch['pieces'], conds=graph_embedding,
+                                  edge_select=batch['edge_select'], golden_edge=batch['golden_edge'],
+                                  return_accu=return_accu, eps=eps)
+            props = batch['props']
+        pred_prop = self.predictor(z)
+        golden = props.reshape(batch_size, -1)[:, self.config['selected_properties']].float()
+        pred_loss = self.pred_loss(pred_prop, golden)
+        return pred_loss, res
+
+    def cal_beta(self):
+        step = self.global_step
+        warmup = self.config['kl_warmup']
+        if step < warmup:
+            beta = 0
+        else:
+            step_beta, anneal_iter = self.config['step_beta'], self.config['kl_anneal_iter']
+            beta = min(self.config['max_beta'], ((step - warmup) // anneal_iter + 1) * step_beta)
+        beta += self.config['beta']
+        return beta
+
+    def weighted_loss(self, pred_loss, rec_loss, kl_loss):
+        alpha = self.config['alpha']
+        beta = self.cal_beta()
+        return alpha * rec_loss + (1 - alpha) * pred_loss + beta * kl_loss
+
+    def training_step(self, batch, batch_idx):
+        st = time.time()
+        pred_loss, rec_losses = self.forward(batch)
+        loss = self.weighted_loss(pred_loss, rec_losses[0], rec_losses[-1])
+        self.log('predictor loss', pred_loss)
+        self.log('reconstruct loss', rec_losses[0])
+        self.log('piece loss', rec_losses[1])
+        self.log('edge loss', rec_losses[2])
+        self.log('kl loss', rec_losses[3])
+        self.log('beta', self.cal_beta())
+        self.total_time += time.time() - st
+        self.log('total time', self.total_time)
+        return loss
+
+    def validation_step(self, batch, batch_idx):
+        pred_loss, rec_losses = self.forward(batch, return_accu=True)
+        rec_losses, accus = rec_losses
+        loss = self.weighted_loss(pred_loss, rec_losses[0], rec_losses[-1])
+        self.log('val_loss', loss)
+        for i, name in enumerate(['piece accu', 'edge accu']):
+            self.log(name, accus[i])
+        return loss
+
+    def validation_epoch_end(self, outputs):
+        return
+
+    def test_step(self, batch, batch_idx):
+        pred_loss, rec_losses = self.forward(batch)
+        loss = self.weighted_loss(pred_loss, rec_losses[0], rec_losses[-1])
+        self.log('test_loss', loss)
+        return loss
+
+    def configure_optimizers(self):
+        optimizer = torch.optim.Adam(self.parameters(), lr=self.config['lr'])
+        scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lambda=lambda epoch: 1 / (epoch + 1))
+        return [optimizer], [scheduler]
+
+    # interface
+    def sample_z(self, n, device=None):
+        return torch.randn(n, self.decoder.latent_dim, device=self.device if device is None else device)
+
+    def inference_single_z(self, z, max_atom_num, add_edge_th, temperature):
+        return self.decoder.inference(z, max_atom_num, add_edge_th, temperature)
+
+    def inference_batch_z(self, zs, max_atom_num, add_edge_th, temperature, constraint_mol=None):
+        return [self.inference_single_z(z, max_atom_num, add_edge_th, temperature) for z in zs]
+
+    def predict_props(self, z):
+        props = self.predictor(z)
+        if len(props.shape) == 1:
+            padded_props = [torch.tensor(0, device=props.device) for _ in PROPS]
+            for i, val in zip(self.config['selected_properties'], props):
+                padded_props[i] = val
+            return torch.stack(padded_props)
+        padded_props = torch.zeros(props.shape[0], len(PROPS), device=props.device)
+        padded_props[:, self.config['selected_properties']] = props
+        return padded_props
+
+    def get_z(self, batch, eps=None):
+        compact = getattr(batch, 'compact', None)
+        if compact is not None:
+            x = self.decoder.embed_atom(compact.cx, compact.cxp, compact.cxpos)
+            _, all_x = self.encoder.embed_node(x, compact.csr)
+            graph_embedding = self.encoder.embed_graph(all_x, compact.segments)
+        else:
+            x = self.decoder.embed_atom(batch['x'], batch['x_pieces'], batch['x_pos'])
+            batch_size, node_num, node_dim = x.shape
+            graph_ids = torch.repeat_interleave(torch.arange(0, batch_size, device=x.device), node_num)
+            _, all_x = self.encoder.embed_node(x.view(-1, node_dim), batch['edge_index'], batch['edge_attr'])
+            graph_embedding = self.encoder.embed_graph(all_x, graph_ids, batch['atom_mask'].flatten())
+        z_vecs, _ = self.decoder.rsample(graph_embedding, eps)
+        return z_vecs
+
+    def get_z_from_return_data(self, step1_res, eps=None):
+        """The reference takes an rdkit Mol and runs process_step1 on it
+        (src/pl_models/ps_vae_model.py:175-181); without RDKit the entry is the process_step1
+        dict itself."""
+        step2_res = BPEMolDataset.process_step2(step1_res, self.tokenizer)
+        res = BPEMolDataset.process_step3([step2_res], self.tokenizer, device=self.device)
+        return self.get_z(res, eps).squeeze()
+
+    get_z_from_mol = get_z_from_return_data
+
+    def return_data_to_mol(self, data):
+        return data
+
+    def get_dataloader(self, fname, **kwargs):
+        return get_dataloader(fname, self.tokenizer, **kwargs)
+
+    def get_from_batch(self, batch, key):
+        if key == 'batch_size':
+            return getattr(batch, 'batch_size', None) or batch['x'].shape[0]
+        elif key == 'props':
+            return batch['props']

@@ -1,0 +1,418 @@
+"""Per-kernel parity on the GPU: every HIP entry point, called through the C-ABI binding,
+against the CPU oracle / a plain fp32-or-better PyTorch restatement on the same inputs.
+
+Tolerances: integer outputs bit-exact; fp32 within 1e-5 relative to the magnitude of the
+reference tensor (the tolerance BASELINE.json's north_star states)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_npz, sub
+from oracle import collate_ref, model_ref
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-5
+
+
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail('GPU tests need a GPU (run with -m "not gpu" on CPU-only machines)')
+    return torch.device('cuda:0')
+
+
+def close(got, want, rel=REL, what=''):
+    got = got.detach().double().cpu()
+    want = want.detach().double().cpu()
+    assert got.shape == want.shape, f'{what}: shape {tuple(got.shape)} vs {tuple(want.shape)}'
+    scale = want.abs().max().item() if want.numel() else 0.0
+    err = (got - want).abs().max().item() if want.numel() else 0.0
+    assert err <= rel * max(scale, 1e-30) + 1e-30, f'{what}: max abs err {err:.3e} vs scale {scale:.3e}'
+
+
+# ------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize('M,N,K', [(1, 1, 1), (7, 5, 3), (64, 64, 32), (130, 300, 200), (1000, 300, 300),
+                                   (333, 656, 328), (257, 4, 656), (40, 56, 400), (129, 65, 33)])
+def test_gemm_forward_shapes(M, N, K):
+    from ps_vae_amd import hip
+    d = dev()
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g)
+    b = torch.randn(N, generator=g)
+    xd, wd, bd = x.to(d), w.to(d), b.to(d)
+    out = torch.empty(M, N, device=d)
+    hip.gemm(M, N, K, xd, K, 1, wd, 1, K, out, N, bias=bd, relu=True)
+    close(out, torch.relu(x.double() @ w.double().t() + b.double()), what='relu(xW^T+b)')
+    # input-gradient form dY W with the ReLU mask applied to dY while loading
+    gy = torch.randn(M, N, generator=g)
+    act = torch.relu(torch.randn(M, N, generator=g))
+    gx = torch.empty(M, K, device=d)
+    hip.gemm(M, K, N, gy.to(d), N, 1, wd, K, 1, gx, K, amask=act.to(d))
+    close(gx, (gy.double() * (act > 0)) @ w.double(), what='dX')
+    # weight-gradient form dY^T X, split-K chosen by the library and forced
+    for split in (0, 1, 5):
+        gw = torch.full((N, K), 3.0, device=d)
+        hip.gemm(N, K, M, gy.to(d), 1, N, xd, K, 1, gw, K, amask=act.to(d), split_k=split, accumulate=True)
+        close(gw, 3.0 + (gy.double() * (act > 0)).t() @ x.double(), what=f'dW split {split}')
+
+
+def test_gemm_strided_output_and_operands():
+    from ps_vae_amd import hip
+    d = dev()
+    g = torch.Generator().manual_seed(5)
+    big = torch.randn(200, 1200, generator=g)
+    w = torch.randn(300, 300, generator=g)
+    bigd = big.to(d)
+    out = torch.zeros(200, 1200, device=d)
+    xs = bigd[:, 300:600]                      # row stride 1200
+    hip.gemm(200, 300, 300, xs, 1200, 1, w.to(d), 1, 300, out[:, 600:900], 1200)
+    want = torch.zeros(200, 1200, dtype=torch.float64)
+    want[:, 600:900] = big[:, 300:600].double() @ w.double().t()
+    close(out, want, what='strided slot')
+
+
+def test_gemm_large_split_k():
+    from ps_vae_amd import hip
+    d = dev()
+    g = torch.Generator().manual_seed(9)
+    M = 20000
+    gy = torch.randn(M, 300, generator=g)
+    x = torch.randn(M, 200, generator=g)
+    gw = torch.empty(300, 200, device=d)
+    hip.gemm(300, 200, M, gy.to(d), 1, 300, x.to(d), 200, 1, gw, 200, split_k=0)
+    close(gw, gy.double().t() @ x.double(), what='dW K=20000')
+
+
+def test_colsum():
+    from ps_vae_amd import hip
+    d = dev()
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(5000, 328, generator=g)
+    m = torch.randn(5000, 328, generator=g)
+    out = torch.ones(328, device=d)
+    hip.colsum(x.to(d), out, mask=m.to(d), accumulate=True)
+    close(out, 1.0 + (x.double() * (m > 0)).sum(0), what='masked colsum')
+    out2 = torch.empty(328, device=d)
+    hip.colsum(x.to(d), out2)
+    close(out2, x.double().sum(0), what='colsum')
+
+
+# ------------------------------------------------------------------ Linear autograd
+@pytest.mark.parametrize('relu', [False, True])
+def test_linear_autograd(relu):
+    from ps_vae_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(777, 200, generator=g, requires_grad=True)
+    w = (torch.randn(300, 200, generator=g) * 0.1).requires_grad_()
+    b = torch.randn(300, generator=g, requires_grad=True)
+    gy = torch.randn(777, 300, generator=g)
+    y = torch.nn.functional.linear(x.double(), w.double(), b.double())
+    y = torch.relu(y) if relu else y
+    y.backward(gy.double())
+    xd, wd, bd = (t.detach().to(d).requires_grad_() for t in (x, w, b))
+    yd = ops.linear(xd, wd, bd, relu=relu)
+    yd.backward(gy.to(d))
+    close(yd, y, what='y')
+    close(xd.grad, x.grad, what='dx')
+    close(wd.grad, w.grad, what='dw')
+    close(bd.grad, b.grad, what='db')
+
+
+# ------------------------------------------------------------------ graphs for the GNN kernels
+def random_graph(V, H, C, seed, max_deg=4):
+    rng = np.random.default_rng(seed)
+    src, dst, cls = [], [], []
+    for i in range(V):
+        for _ in range(rng.integers(0, max_deg + 1)):
+            j = int(rng.integers(max(0, i - 20), min(V, i + 20)))
+            src.append(j), dst.append(i), cls.append(int(rng.integers(0, C)))
+    ei = torch.tensor([src, dst], dtype=torch.long).reshape(2, -1)
+    attr = torch.nn.functional.one_hot(torch.tensor(cls, dtype=torch.long), C)
+    g = torch.Generator().manual_seed(seed)
+    return ei, attr, torch.randn(V, H, generator=g), torch.randn(C, H, generator=g) * 0.5
+
+
+@pytest.mark.parametrize('V,H,C', [(1, 4, 1), (50, 36, 4), (700, 300, 4), (333, 128, 7)])
+def test_gine_aggregate_fwd_bwd(V, H, C):
+    from ps_vae_amd import ops
+    d = dev()
+    ei, attr, x, table = random_graph(V, H, C, seed=V + H)
+    x.requires_grad_(), table.requires_grad_()
+    e = attr.float() @ table
+    out = model_ref.gine_aggregate(x, ei[0], ei[1], e)
+    gy = torch.randn(V, H, generator=torch.Generator().manual_seed(1))
+    out.backward(gy)
+    csr = ops.Csr.from_edge_index(ei.to(d), attr.to(d), V)
+    xd, td = x.detach().to(d).requires_grad_(), table.detach().to(d).requires_grad_()
+    outd = ops.gine_aggregate(xd, td, csr)
+    outd.backward(gy.to(d))
+    close(outd, out, what='aggregate')
+    close(xd.grad, x.grad, what='d aggregate / dx')
+    close(td.grad, table.grad, what='d aggregate / dtable')
+
+
+def test_gine_aggregate_strided_rows():
+    from ps_vae_amd import hip, ops
+    d = dev()
+    V, H, C = 200, 300, 4
+    ei, attr, x, table = random_graph(V, H, C, seed=3)
+    want = model_ref.gine_aggregate(x, ei[0], ei[1], attr.float() @ table)
+    csr = ops.Csr.from_edge_index(ei.to(d), attr.to(d), V)
+    wide = torch.zeros(V, 1200, device=d)
+    wide[:, 300:600] = x.to(d)
+    hip.gine_aggregate_fwd(wide[:, 300:600], table.to(d), csr.row_ptr, csr.col, csr.cls, wide[:, 600:900])
+    close(wide[:, 600:900], want, what='aggregate into a slot')
+
+
+# ------------------------------------------------------------------ small fused ops
+def test_embed_atom_fwd_bwd():
+    from ps_vae_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(4)
+    V = 3000
+    ea, ep, eq = torch.randn(11, 50, generator=g), torch.randn(302, 100, generator=g), torch.randn(50, 50, generator=g)
+    x = torch.randint(0, 11, (V,), generator=g)
+    xp = torch.randint(0, 302, (V,), generator=g)
+    xq = torch.randint(0, 50, (V,), generator=g)
+    for t in (ea, ep, eq):
+        t.requires_grad_()
+    want = torch.cat([ea[x], ep[xp], eq[xq]], dim=-1)
+    gy = torch.randn(V, 200, generator=g)
+    want.backward(gy)
+    tabs = [t.detach().to(d).requires_grad_() for t in (ea, ep, eq)]
+    got = ops.embed_atom(x.to(d).int(), xp.to(d).int(), xq.to(d).int(), *tabs)
+    got.backward(gy.to(d))
+    assert torch.equal(got.cpu(), want.detach())
+    for t, r, name in zip(tabs, (ea, ep, eq), ('atom', 'piece', 'pos')):
+        close(t.grad, r.grad, rel=2e-5, what=f'd embed / d {name} table')
+
+
+def test_segment_sum_fwd_bwd():
+    from ps_vae_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(6)
+    lens = [3, 0, 17, 38, 1, 9]
+    off = np.concatenate([[0], np.cumsum(lens)])
+    V, W = int(off[-1]), 1200
+    x = torch.randn(V, W, generator=g, requires_grad=True)
+    gid = torch.repeat_interleave(torch.arange(len(lens)), torch.tensor(lens))
+    want = torch.zeros(len(lens), W).index_add_(0, gid, x)
+    gy = torch.randn(len(lens), W, generator=g)
+    want.backward(gy)
+    segs = ops.Segments.from_offsets(torch.tensor(off, dtype=torch.int32, device=d))
+    xd = x.detach().to(d).requires_grad_()
+    got = ops.segment_sum(xd, segs)
+    got.backward(gy.to(d))
+    close(got, want, what='segment sum')
+    close(xd.grad, x.grad, what='segment sum backward')
+
+
+def test_rsample_kl_fwd_bwd():
+    from ps_vae_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(8)
+    B, L = 257, 56
+    mean = torch.randn(B, L, generator=g, requires_grad=True)
+    pre = torch.randn(B, L, generator=g, requires_grad=True)
+    eps = torch.randn(B, L, generator=g)
+    lv = -torch.abs(pre)
+    kl = -0.5 * torch.sum(1.0 + lv - mean * mean - torch.exp(lv)) / B
+    z = mean + torch.exp(lv / 2) * eps
+    gz = torch.randn(B, L, generator=g)
+    (z * gz).sum().add(kl * 0.37).backward()
+    md, pd = mean.detach().to(d).requires_grad_(), pre.detach().to(d).requires_grad_()
+    zd, kld = ops.rsample_kl(md, pd, eps.to(d))
+    ((zd * gz.to(d)).sum() + kld * 0.37).backward()
+    close(zd, z, what='z')
+    close(kld, kl, what='kl')
+    close(md.grad, mean.grad, what='d/dmean')
+    close(pd.grad, pre.grad, what='d/dlogvar')
+
+
+def make_pairs(B, N, seed, p=0.15):
+    g = torch.Generator().manual_seed(seed)
+    sel = torch.rand(B, N, N, generator=g) < p
+    sel[1] = False                                  # a graph without any pair
+    return sel
+
+
+def test_pair_gather_fwd_bwd():
+    from ps_vae_amd import ops
+    d = dev()
+    B, N, H, L = 5, 13, 300, 56
+    g = torch.Generator().manual_seed(10)
+    sel = make_pairs(B, N, 10)
+    h = torch.randn(B * N, H, generator=g, requires_grad=True)
+    z = torch.randn(B, L, generator=g, requires_grad=True)
+    b, m, n = sel.nonzero(as_tuple=True)
+    want = torch.cat([h[b * N + m], h[b * N + n], z[b]], dim=-1)
+    gy = torch.randn(want.shape, generator=g)
+    want.backward(gy)
+    pairs = ops.PairList.from_edge_select(sel.to(d))
+    hd, zd = h.detach().to(d).requires_grad_(), z.detach().to(d).requires_grad_()
+    got = ops.pair_gather(hd, zd, pairs)
+    got.backward(gy.to(d))
+    assert torch.equal(got.cpu(), want.detach())
+    close(hd.grad, h.grad, what='d pair / dh')
+    close(zd.grad, z.grad, what='d pair / dz')
+
+
+def test_pair_gather_bwd_many_pairs_per_graph():
+    """More pairs in one graph than one LDS chunk holds (inference-sized candidate sets)."""
+    from ps_vae_amd import ops
+    d = dev()
+    B, N, H, L = 2, 60, 36, 8
+    g = torch.Generator().manual_seed(12)
+    sel = torch.rand(B, N, N, generator=g) < 0.6
+    h = torch.randn(B * N, H, generator=g, requires_grad=True)
+    z = torch.randn(B, L, generator=g, requires_grad=True)
+    b, m, n = sel.nonzero(as_tuple=True)
+    assert (b == 0).sum() > 1024
+    want = torch.cat([h[b * N + m], h[b * N + n], z[b]], dim=-1)
+    gy = torch.randn(want.shape, generator=g)
+    want.backward(gy)
+    pairs = ops.PairList.from_edge_select(sel.to(d))
+    hd, zd = h.detach().to(d).requires_grad_(), z.detach().to(d).requires_grad_()
+    ops.pair_gather(hd, zd, pairs).backward(gy.to(d))
+    close(hd.grad, h.grad, what='d pair / dh')
+    close(zd.grad, z.grad, what='d pair / dz')
+
+
+@pytest.mark.parametrize('P', [0, 1, 5, 4097])
+def test_link_ce_fwd_bwd(P):
+    from ps_vae_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(13 + P)
+    F, C = 656, 4
+    hid = torch.randn(P, F, generator=g, requires_grad=True)
+    w = (torch.randn(C, F, generator=g) * 0.05).requires_grad_()
+    b = torch.randn(C, generator=g, requires_grad=True)
+    gold = torch.randint(0, C, (P,), generator=g)
+    logits = torch.nn.functional.linear(hid, w, b)
+    hd, wd, bd = (t.detach().to(d).requires_grad_() for t in (hid, w, b))
+    lossd, logitsd, okd = ops.link_ce(hd, wd, bd, gold.to(d).int())
+    if P == 0:
+        assert torch.isnan(lossd).item()      # torch: mean over an empty batch
+        return
+    loss = torch.nn.functional.cross_entropy(logits, gold)
+    (loss * 0.1).backward()
+    (lossd * 0.1).backward()
+    close(logitsd, logits, what='logits')
+    close(lossd, loss, what='CE')
+    assert okd.item() == (logits.argmax(-1) == gold).sum().item()
+    close(hd.grad, hid.grad, what='d CE / d hidden')
+    close(wd.grad, w.grad, what='d CE / dW')
+    close(bd.grad, b.grad, what='d CE / db')
+
+
+def test_link_infer():
+    from ps_vae_amd import hip
+    d = dev()
+    g = torch.Generator().manual_seed(14)
+    logits = torch.randn(1000, 4, generator=g) * 3
+    prob = torch.softmax(logits, -1)
+    conf, et = prob.max(-1)
+    c = torch.empty(1000, device=d)
+    t = torch.empty(1000, dtype=torch.int32, device=d)
+    k = torch.empty(1000, dtype=torch.uint8, device=d)
+    hip.link_infer(logits.to(d), 0.5, 0, c, t, k)
+    close(c, conf, what='confidence')
+    assert torch.equal(t.cpu().long(), et)
+    # identical to the host rule except where conf sits within rounding of the threshold
+    want = (conf >= 0.5) & (et != 0)
+    near = (conf - 0.5).abs() < 1e-6
+    assert torch.equal(k.cpu().bool()[~near], want[~near])
+
+
+def test_exclusive_scan():
+    from ps_vae_amd import hip
+    d = dev()
+    for n in (0, 1, 63, 1024, 1025, 5000):
+        x = torch.randint(0, 100, (n,), dtype=torch.int32)
+        out = torch.empty(n + 1, dtype=torch.int32, device=d)
+        hip.exclusive_scan(x.to(d), out)
+        want = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(x.long(), 0)])
+        assert torch.equal(out.cpu().long(), want)
+
+
+# ------------------------------------------------------------------ collation
+REF_KEYS = ['x', 'x_pieces', 'x_pos', 'atom_mask', 'pieces', 'edge_index', 'edge_attr', 'edge_select',
+            'golden_edge', 'in_piece_edge_idx']
+COMPACT_KEYS = ['cx', 'cxp', 'cxpos', 'row_ptr', 'col', 'cls', 'in_row_ptr', 'in_col', 'in_cls',
+                'pair_src', 'pair_dst', 'pair_graph', 'golden']
+
+
+def compact_arrays(c):
+    return {'node_off': c.node_off, 'cx': c.cx, 'cxp': c.cxp, 'cxpos': c.cxpos,
+            'row_ptr': c.csr.row_ptr, 'col': c.csr.col, 'cls': c.csr.cls,
+            'in_row_ptr': c.csr_in.row_ptr, 'in_col': c.csr_in.col, 'in_cls': c.csr_in.cls,
+            'pair_src': c.pairs.src, 'pair_dst': c.pairs.dst, 'pair_graph': c.pairs.graph,
+            'golden': c.golden, 'pair_ptr': c.pairs.ptr}
+
+
+def check_collate(step1, uniforms, want, tokenizer):
+    from ps_vae_amd.data.collate import collate_packed
+    from ps_vae_amd.data.packed import PackedMolecules
+    d = dev()
+    packed = PackedMolecules.from_step1(step1)
+    u = torch.from_numpy(np.ascontiguousarray(uniforms if len(uniforms) else np.zeros(1))).to(d)
+    got = collate_packed(packed.to_device(d), np.arange(len(step1)), uniforms=u,
+                         atom_pad=tokenizer.atom_pad_idx(), piece_pad=tokenizer.pad_idx())
+    assert got.num_uniforms == len(uniforms)
+    for k in REF_KEYS:
+        g = got[k].cpu().numpy()
+        w = want[k]
+        if k == 'edge_index' and w.shape[1] == 0:
+            assert g.shape == (2, 0)
+            continue
+        assert g.shape == w.shape and g.dtype == w.dtype, (k, g.shape, w.shape, g.dtype, w.dtype)
+        assert np.array_equal(g, w), k
+    assert np.array_equal(got['props'].cpu().numpy(), want['props'].astype(np.float32).reshape(len(step1), -1))
+    wc = collate_ref.compact_from_reference({k: want[k] for k in REF_KEYS})
+    gc = compact_arrays(got.compact)
+    for k, w in wc.items():
+        g = gc[k].cpu().numpy()
+        assert g.shape == w.shape and np.array_equal(g, w), k
+
+
+@pytest.mark.parametrize('name', ['single_atom', 'one_piece_only', 'no_bond_only', 'mixed_small',
+                                  'zinc_ragged', 'qm9_ragged', 'max_size_38'])
+def test_collate_golden_bit_exact(name, tokenizer):
+    with open(os.path.join(GOLDEN, 'collate_cases.json')) as f:
+        step1 = json.load(f)[name]
+    gold = sub(load_npz('collate_cases.npz'), name)
+    check_collate(step1, gold['uniforms'], gold, tokenizer)
+
+
+def test_collate_batch_512_vs_oracle(tokenizer):
+    from ps_vae_amd.data.synthetic import synthetic_step1
+    step1 = synthetic_step1(512, seed=77, shape='zinc')
+    rng = np.random.default_rng(5)
+    uniforms = rng.random(400 * 512)
+    want, used = collate_ref.collate(step1, uniforms, piece_pad=tokenizer.pad_idx())
+    check_collate(step1, uniforms[:used], want, tokenizer)
+
+
+def test_collate_subset_order_and_large_molecule(tokenizer):
+    """Batches are arbitrary id subsets of a packed dataset; a 120-atom molecule exercises
+    many 256-cell chunks and the LDS sizing."""
+    from ps_vae_amd.data.collate import collate_packed
+    from ps_vae_amd.data.packed import PackedMolecules
+    from ps_vae_amd.data.synthetic import random_molecule, synthetic_step1
+    d = dev()
+    step1 = synthetic_step1(20, seed=3, shape='zinc')
+    step1.append(random_molecule(np.random.default_rng(1), 120))
+    packed = PackedMolecules.from_step1(step1)
+    ids = [20, 3, 3, 17, 0]
+    uniforms = np.random.default_rng(9).random(40000)
+    want, used = collate_ref.collate([step1[i] for i in ids], uniforms, piece_pad=tokenizer.pad_idx())
+    got = collate_packed(packed.to_device(d), ids, uniforms=torch.from_numpy(uniforms).to(d),
+                         atom_pad=tokenizer.atom_pad_idx(), piece_pad=tokenizer.pad_idx())
+    assert got.num_uniforms == used
+    for k in REF_KEYS:
+        assert np.array_equal(got[k].cpu().numpy(), want[k]), k

@@ -1,0 +1,208 @@
+"""End-to-end parity on the GPU: the HIP-backed modules (reference API) against the golden
+vectors the reference produced and against the CPU oracle on the same batches."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_npz, sub
+from oracle import collate_ref, model_ref
+from test_gpu_kernels import close, dev
+
+pytestmark = pytest.mark.gpu
+
+SMALL = dict(latent_dim=8, predictor_hidden_dim=16, node_hidden_dim=36, graph_embedding_dim=40,
+             atom_embedding_dim=6, piece_embedding_dim=12, pos_embedding_dim=6, piece_hidden_dim=20)
+
+
+def hip_model(tokenizer, state=None, seed=None, **dims):
+    from ps_vae_amd.pl_models import PSVAEModel
+    from ps_vae_amd.utils.nn_utils import build_config, default_args
+    cfg = build_config(default_args(**dims), tokenizer)
+    if seed is not None:
+        torch.manual_seed(seed)
+    model = PSVAEModel(cfg, tokenizer)
+    if state is not None:
+        res = model.load_state_dict(state, strict=True)
+        assert not res.missing_keys and not res.unexpected_keys
+    return model.to(dev()), cfg
+
+
+def to_dev_batch(npb):
+    return {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev()) for k, v in npb.items()}
+
+
+def small_step1():
+    from ps_vae_amd.data.synthetic import synthetic_step1
+    return synthetic_step1(5, seed=31, shape='zinc') + synthetic_step1(3, seed=32, shape='qm9')
+
+
+def test_state_dict_keys_match_reference(tokenizer):
+    gold = load_npz('model_small.npz')
+    model, _ = hip_model(tokenizer, **SMALL)
+    assert set(model.state_dict().keys()) == set(sub(gold, 'state').keys())
+    for k, v in model.state_dict().items():
+        assert tuple(v.shape) == gold[f'state/{k}'].shape, k
+
+
+@pytest.mark.parametrize('path', ['reference_dict', 'compact'])
+def test_small_model_against_reference_golden(tokenizer, path):
+    gold = load_npz('model_small.npz')
+    state = {k: torch.from_numpy(v) for k, v in sub(gold, 'state').items()}
+    model, cfg = hip_model(tokenizer, state=state, **SMALL)
+    eps = torch.from_numpy(gold['eps']).to(dev())
+    if path == 'reference_dict':
+        batch = to_dev_batch(sub(gold, 'batch'))
+        with torch.no_grad():
+            x = model.decoder.embed_atom(batch['x'], batch['x_pieces'], batch['x_pos'])
+            assert torch.equal(x.cpu(), torch.from_numpy(gold['act/embed_atom']))
+            B, N, D = x.shape
+            last, all_x = model.encoder.embed_node(x.view(-1, D), batch['edge_index'], batch['edge_attr'])
+            close(last, torch.from_numpy(gold['act/enc_last']), what='encoder last iterate')
+            close(all_x, torch.from_numpy(gold['act/enc_all_x']), what='encoder all_x')
+            gids = torch.repeat_interleave(torch.arange(B, device=dev()), N)
+            genc = model.encoder.embed_graph(all_x, gids, batch['atom_mask'].flatten())
+            close(genc, torch.from_numpy(gold['act/graph_embedding']), what='graph embedding')
+            z, kl = model.decoder.rsample(genc, eps)
+            close(z, torch.from_numpy(gold['act/z']), what='z')
+            close(kl, torch.from_numpy(gold['act/kl']), what='kl')
+            idx = batch['in_piece_edge_idx']
+            h, _ = model.decoder.graph_embedding.embed_node(x.view(-1, D), batch['edge_index'][:, idx],
+                                                            batch['edge_attr'][idx])
+            close(h, torch.from_numpy(gold['act/dec_node_embedding']), what='decoder node embedding')
+    else:
+        from ps_vae_amd.data.collate import collate_packed
+        from ps_vae_amd.data.packed import PackedMolecules
+        packed = PackedMolecules.from_step1(small_step1())
+        u = torch.from_numpy(gold['uniforms']).to(dev())
+        batch = collate_packed(packed.to_device(dev()), np.arange(len(packed)), uniforms=u,
+                               atom_pad=tokenizer.atom_pad_idx(), piece_pad=tokenizer.pad_idx(),
+                               reference_layout=False)
+        assert batch.compact is not None and 'x' not in batch
+
+    pred_loss, (losses, accus) = model(batch, return_accu=True, eps=eps)
+    rec, piece, edge, kl = losses
+    loss = model.weighted_loss(pred_loss, rec, kl)
+    for name, val in [('total', loss), ('pred', pred_loss), ('rec', rec), ('piece', piece), ('edge', edge), ('kl', kl)]:
+        np.testing.assert_allclose(val.item(), gold[f'loss/{name}'], rtol=1e-5, err_msg=name)
+    assert accus[0] == pytest.approx(float(gold['accu/piece']))
+    assert accus[1] == pytest.approx(float(gold['accu/edge']))
+    loss.backward()
+    no_grad = set(gold['no_grad_params'].tolist())
+    for k, p in model.named_parameters():
+        if k in no_grad:
+            assert p.grad is None, k
+            continue
+        close(p.grad, torch.from_numpy(gold[f'grad/{k}']), rel=2e-5, what=f'grad {k}')
+    opt = torch.optim.Adam(model.parameters(), lr=cfg['lr'])
+    total = torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
+    np.testing.assert_allclose(total.item(), gold['grad_total_norm'], rtol=1e-5)
+    opt.step()
+    for k, v in model.state_dict().items():
+        close(v, torch.from_numpy(gold[f'after_step/{k}']), rel=2e-5, what=f'after step {k}')
+
+
+def test_default_width_model_against_reference_golden(tokenizer):
+    """H=300, G=400, L=56 — the awkward widths the kernels are built for."""
+    gold = load_npz('model_default.npz')
+    model, _ = hip_model(tokenizer, seed=int(gold['seed']))
+    batch = to_dev_batch(sub(gold, 'batch'))
+    eps = torch.from_numpy(gold['eps']).to(dev())
+    pred_loss, (rec, piece, edge, kl) = model(batch, eps=eps)
+    loss = model.weighted_loss(pred_loss, rec, kl)
+    for name, val in [('total', loss), ('pred', pred_loss), ('rec', rec), ('piece', piece), ('edge', edge), ('kl', kl)]:
+        np.testing.assert_allclose(val.item(), gold[f'loss/{name}'], rtol=1e-5, err_msg=name)
+    loss.backward()
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            assert k in set(gold['no_grad_params'].tolist())
+            continue
+        np.testing.assert_allclose(p.grad.norm().item(), gold[f'gradnorm/{k}'], rtol=1e-4, err_msg=k)
+
+
+def test_default_width_batch_256_against_oracle(tokenizer):
+    """A larger batch through the compact path vs the CPU oracle on the reference layout of
+    the same collation: every loss and every parameter gradient."""
+    from ps_vae_amd.data.collate import collate_packed
+    from ps_vae_amd.data.packed import PackedMolecules
+    from ps_vae_amd.data.synthetic import synthetic_step1
+    B = 256
+    step1 = synthetic_step1(B, seed=123, shape='zinc')
+    uniforms = np.random.default_rng(1).random(500 * B)
+    want_batch, used = collate_ref.collate(step1, uniforms, piece_pad=tokenizer.pad_idx())
+    cfg = model_ref.default_config(tokenizer)
+    torch.manual_seed(7)
+    ref = model_ref.PSVAEModel(cfg, tokenizer)
+    model, _ = hip_model(tokenizer, state=ref.state_dict())
+    eps = torch.randn(B, 56, generator=torch.Generator().manual_seed(2))
+    tb = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in want_batch.items()}
+    pl, (rec, piece, edge, kl) = ref(tb, eps)
+    ref_loss = ref.weighted_loss(pl, rec, kl)
+    ref_loss.backward()
+
+    packed = PackedMolecules.from_step1(step1)
+    batch = collate_packed(packed.to_device(dev()), np.arange(B), uniforms=torch.from_numpy(uniforms).to(dev()),
+                           atom_pad=tokenizer.atom_pad_idx(), piece_pad=tokenizer.pad_idx(), reference_layout=False)
+    assert batch.num_uniforms == used
+    gpl, (grec, gpiece, gedge, gkl) = model(batch, eps=eps.to(dev()))
+    loss = model.weighted_loss(gpl, grec, gkl)
+    loss.backward()
+    for name, a, b in [('total', loss, ref_loss), ('pred', gpl, pl), ('piece', gpiece, piece), ('edge', gedge, edge),
+                       ('kl', gkl, kl)]:
+        np.testing.assert_allclose(a.item(), b.item(), rtol=1e-5, err_msg=name)
+    refp = dict(ref.named_parameters())
+    for k, p in model.named_parameters():
+        if refp[k].grad is None:
+            assert p.grad is None, k
+            continue
+        close(p.grad, refp[k].grad, rel=3e-5, what=f'grad {k}')
+
+
+def test_infer_links_against_reference_golden(tokenizer):
+    gold = load_npz('infer_links.npz')
+    state = {k: torch.from_numpy(v) for k, v in sub(gold, 'state').items()}
+    model, _ = hip_model(tokenizer, state=state, **SMALL)
+    th = float(gold['add_edge_th'])
+    for c in range(int(gold['num_cases'])):
+        g = sub(gold, f'case{c}')
+        groups, p = [], 0
+        for ln in g['groups_len']:
+            groups.append(g['groups_flat'][p:p + ln].tolist())
+            p += ln
+        pairs, conf, etype, order = model.decoder.infer_links(
+            torch.from_numpy(g['z']), torch.from_numpy(g['x']), torch.from_numpy(g['x_pieces']),
+            torch.from_numpy(g['x_pos']), torch.from_numpy(g['edge_index']), torch.from_numpy(g['edge_attr']),
+            groups, th)
+        assert np.array_equal(pairs.cpu().numpy(), g['pairs'])
+        close(conf, torch.from_numpy(g['conf']), rel=2e-5, what='confidence')
+        assert np.array_equal(etype.cpu().numpy(), g['etype'])
+        # the kept set and its order agree wherever confidences are not within rounding of
+        # each other or of the threshold
+        want = g['order'].tolist()
+        gc = g['conf']
+        safe = all(abs(gc[i] - th) > 1e-5 for i in range(len(gc)))
+        srt = np.sort(gc[want])[::-1] if len(want) else np.zeros(0)
+        distinct = len(want) < 2 or float(np.min(-np.diff(srt))) > 1e-6
+        if safe and distinct:
+            assert order == want
+        else:
+            assert sorted(order) == sorted(want) or not safe
+
+
+def test_process_step3_same_seed_as_reference(tokenizer):
+    """BPEMolDataset.process_step3 draws random.random() in the reference's order: under the
+    seed the golden batch was made with it must return that batch."""
+    import json
+    import os
+    import random
+    from conftest import GOLDEN
+    from ps_vae_amd.data.bpe_dataset import BPEMolDataset
+    with open(os.path.join(GOLDEN, 'collate_cases.json')) as f:
+        cases = json.load(f)
+    gold_all = load_npz('collate_cases.npz')
+    for i, (name, step1) in enumerate(cases.items()):
+        gold = sub(gold_all, name)
+        random.seed(100 + i)
+        step2 = [BPEMolDataset.process_step2(d, tokenizer) for d in step1]
+        got = BPEMolDataset.process_step3(step2, tokenizer, device=dev())
+        for k in ('edge_select', 'golden_edge', 'edge_attr', 'in_piece_edge_idx', 'x_pieces', 'x_pos'):
+            assert np.array_equal(got[k].cpu().numpy(), gold[k]), (name, k)
