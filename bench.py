@@ -1,0 +1,185 @@
+"""Benchmark of the PS-VAE train step on MI355X (one process per GPU).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = collate a batch of synthetic ZINC-shaped molecules (already packed in HBM) on the
+GPU, forward, backward, gradient all-reduce (N > 1), global-norm clip, Adam.  Workload:
+BASELINE.json configs[2] ("synthetic ZINC-shaped graphs, batch 4096") per GPU, weak scaling.
+Rank 0 prints ONE JSON line (see README / DESIGN.md for the fields).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E, spec
+MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32, dense
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=4096, help='molecules per GPU per step')
+    ap.add_argument('--dataset', type=int, default=0, help='synthetic molecules per rank (default 4x batch)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-batch', type=int, default=256)
+    ap.add_argument('--cpu-steps', type=int, default=3)
+    return ap.parse_args()
+
+
+def make_dataset(num, seed, tok, device):
+    import ps_vae_amd  # noqa: F401
+    from ps_vae_amd.data.bpe_dataset import BPEMolDataset
+    from ps_vae_amd.data.packed import PackedMolecules
+    from ps_vae_amd.data.synthetic import synthetic_step1
+    cache = f'/tmp/psvae_synth_zinc_{num}_{seed}.npz'
+    if os.path.exists(cache):
+        packed = PackedMolecules.load(cache)
+    else:
+        packed = PackedMolecules.from_step1(synthetic_step1(num, seed=seed, shape='zinc'))
+        try:
+            packed.save(cache)
+        except OSError:
+            pass
+    return BPEMolDataset(None, tok, device=device, data=packed)
+
+
+def cpu_baseline(tok, batch, steps):
+    """The CPU oracle (oracle/: pure-Python collation restatement + plain PyTorch fp32 model,
+    clip, Adam) on this machine's host cores, on a bounded sample of the same workload."""
+    from oracle import collate_ref, model_ref
+    from ps_vae_amd.data.synthetic import synthetic_step1
+    torch.manual_seed(2021)
+    model = model_ref.PSVAEModel(model_ref.default_config(tok), tok)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    rng = np.random.default_rng(0)
+    mols = synthetic_step1(batch * (steps + 1), seed=99, shape='zinc')
+    t_collate = t_model = 0.0
+    for s in range(steps + 1):
+        chunk = mols[s * batch:(s + 1) * batch]
+        t0 = time.perf_counter()
+        b, _ = collate_ref.collate(chunk, rng.random(700 * batch), piece_pad=tok.pad_idx())
+        tb = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in b.items()}
+        t1 = time.perf_counter()
+        model_ref.train_step(model, opt, tb, torch.randn(batch, 56))
+        t2 = time.perf_counter()
+        if s > 0:            # first step is warm-up
+            t_collate += t1 - t0
+            t_model += t2 - t1
+    total = t_collate + t_model
+    return {'value': round(batch * steps / total, 2), 'unit': 'molecules/s', 'cores': torch.get_num_threads(),
+            'kind': 'port',
+            'sample': f'{steps} train steps of batch {batch} (same synthetic ZINC-shaped generator), '
+                      f'collation + forward + backward + clip + Adam, after 1 warm-up step',
+            'collate_molecules_per_s_1core': round(batch * steps / t_collate, 2),
+            'model_step_molecules_per_s': round(batch * steps / t_model, 2)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    import ps_vae_amd  # noqa: F401
+    from ps_vae_amd import hip
+    from ps_vae_amd.dist import FlatGradSync
+    from ps_vae_amd.pl_models import PSVAEModel
+    from ps_vae_amd.utils.nn_utils import build_config, default_args
+    from ps_vae_amd.utils.tokenizer import Tokenizer
+
+    tok = Tokenizer()
+    cfg_args = default_args()
+    torch.manual_seed(2021)                       # identical initial weights on every rank
+    model = PSVAEModel(build_config(cfg_args, tok), tok).to(dev)
+    sync = FlatGradSync(model.parameters())
+    opt = torch.optim.Adam(model.parameters(), lr=cfg_args.lr, fused=True)
+    B = args.batch
+    dataset = make_dataset(args.dataset or 4 * B, 2021 + rank, tok, dev)
+    rng = np.random.default_rng(2021 + rank)
+    torch.manual_seed(2021 + rank)                # per-rank streams for eps / negative sampling
+
+    def step():
+        ids = rng.choice(len(dataset), size=B, replace=False)
+        batch = dataset.collate_ids(ids)
+        sync.zero_grad()
+        loss = model.training_step(batch, 0)
+        loss.backward()
+        sync.sync()
+        sync.clip_grad_norm_(cfg_args.grad_clip)
+        opt.step()
+        model.global_step += 1
+        return batch
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    hip.PROFILE = {}
+    fence()
+    t0 = time.perf_counter()
+    stats = {'V': 0, 'E': 0, 'Ein': 0, 'P': 0}
+    for _ in range(args.steps):
+        b = step()
+        c = b.compact
+        stats['V'] += c.num_nodes
+        stats['E'] += c.csr.col.numel()
+        stats['Ein'] += c.csr_in.col.numel()
+        stats['P'] += len(c.pairs)
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof, hip.PROFILE = hip.PROFILE, None
+    final_loss = float(model.logged['reconstruct loss'])
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = world * B * args.steps / elapsed
+        out = {
+            'metric': 'molecules/sec per PS-VAE train step', 'value': round(value, 1), 'unit': 'molecules/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'data': 'synthetic ZINC-shaped molecules (~23 atoms, ~24 bonds), random-init weights',
+            'config': {'workload': 'BASELINE.json configs[2]: synthetic ZINC-shaped graphs, batch 4096 per GPU, '
+                                   'full train step (GPU collation + encoder + latent + link predictor + piece LM '
+                                   '+ backward + all-reduce + clip + Adam)',
+                       'batch_per_gpu': B, 'global_batch': B * world, 'parallelism': f'dp{world}',
+                       'atoms_per_step': stats['V'] // args.steps, 'pairs_per_step': stats['P'] // args.steps},
+            'rec_loss_last_step': round(final_loss, 5),
+        }
+        out.update(hip.roofline_report(prof, HBM_PEAK_GBS, MFMA_F32_PEAK_TFLOPS))
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(tok, args.cpu_batch, args.cpu_steps)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -85,36 +85,54 @@ def collate_packed(dpacked, ids, uniforms=None, atom_pad=10, piece_pad=300, num_
     P = int(pair_off[B].item())          # the one device->host read of collation
 
     i32, i64, u8 = torch.int32, torch.int64, torch.uint8
-    ref, cmp_ = {}, {}
-    ref['pieces'] = torch.empty(B, S, dtype=i64, device=dev)
-    ref['props'] = torch.empty(B, 3, dtype=torch.float32, device=dev)
+
+    backing = {}
+
+    class _Out(dict):
+        # A zero-element tensor reports a NULL data pointer, which the C ABI reads as "skip
+        # this output": every output is backed by at least one element and the backing
+        # tensor is what crosses the ABI; the dict holds the exact-shape views.
+        def __setitem__(self, key, shape_dtype):
+            shape, dtype = shape_dtype
+            n = int(np.prod(shape))
+            buf = torch.empty(max(n, 1), dtype=dtype, device=dev)
+            backing[key] = buf
+            dict.__setitem__(self, key, buf[:n].view(*shape))
+
+    def alloc(shape, dtype):
+        return shape, dtype
+
+    ref, cmp_ = _Out(), _Out()
+    ref['pieces'] = alloc((B, S), i64)
+    ref['props'] = alloc((B, 3), torch.float32)
     if reference_layout:
         for k in ('x', 'x_pieces', 'x_pos'):
-            ref[k] = torch.empty(B, N, dtype=i64, device=dev)
-        ref['atom_mask'] = torch.empty(B, N, dtype=u8, device=dev)
-        ref['edge_index'] = torch.empty(2, E, dtype=i64, device=dev)
-        ref['edge_attr'] = torch.empty(E, num_bond_type, dtype=i64, device=dev)
-        ref['edge_select'] = torch.empty(B, N, N, dtype=u8, device=dev)
-        ref['golden_edge'] = torch.empty(P, dtype=i64, device=dev)
-        ref['in_piece_edge_idx'] = torch.empty(Ein, dtype=i64, device=dev)
+            ref[k] = alloc((B, N), i64)
+        ref['atom_mask'] = alloc((B, N), u8)
+        ref['edge_index'] = alloc((2, E), i64)
+        ref['edge_attr'] = alloc((E, num_bond_type), i64)
+        ref['edge_select'] = alloc((B, N, N), u8)
+        ref['golden_edge'] = alloc((P,), i64)
+        ref['in_piece_edge_idx'] = alloc((Ein,), i64)
     if compact_layout:
         for k in ('cx', 'cxp', 'cxpos'):
-            cmp_[k] = torch.empty(V, dtype=i32, device=dev)
-        cmp_['row_ptr'] = torch.empty(V + 1, dtype=i32, device=dev)
-        cmp_['col'] = torch.empty(E, dtype=i32, device=dev)
-        cmp_['cls'] = torch.empty(E, dtype=u8, device=dev)
-        cmp_['in_row_ptr'] = torch.empty(V + 1, dtype=i32, device=dev)
-        cmp_['in_col'] = torch.empty(Ein, dtype=i32, device=dev)
-        cmp_['in_cls'] = torch.empty(Ein, dtype=u8, device=dev)
+            cmp_[k] = alloc((V,), i32)
+        cmp_['row_ptr'] = alloc((V + 1,), i32)
+        cmp_['col'] = alloc((E,), i32)
+        cmp_['cls'] = alloc((E,), u8)
+        cmp_['in_row_ptr'] = alloc((V + 1,), i32)
+        cmp_['in_col'] = alloc((Ein,), i32)
+        cmp_['in_cls'] = alloc((Ein,), u8)
         for k in ('pair_src', 'pair_dst', 'pair_graph', 'golden32'):
-            cmp_[k] = torch.empty(P, dtype=i32, device=dev)
+            cmp_[k] = alloc((P,), i32)
         if B == 0 or V == 0:
             cmp_['row_ptr'].zero_()
             cmp_['in_row_ptr'].zero_()
     hip.collate_fill(B, N, S, mol_ids, dpacked,
                      {'node_off': node_off, 'edge_off': edge_off, 'inedge_off': inedge_off,
                       'rng_off': rng_off, 'pair_off': pair_off},
-                     E, uniforms, keep_prob, atom_pad, piece_pad, num_bond_type, ref, cmp_)
+                     E, uniforms, keep_prob, atom_pad, piece_pad, num_bond_type,
+                     {k: backing[k] for k in ref}, {k: backing[k] for k in cmp_})
     out = CollatedBatch()
     if reference_layout:
         out.update(ref)

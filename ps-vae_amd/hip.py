@@ -112,16 +112,88 @@ def workspace(nbytes, device):
     return buf
 
 
+# --------------------------------------------------------------------------- profiling
+# bench.py sets PROFILE = {} around its timed region: every wrapped launch is then bracketed
+# by two events on the launch stream (PyTorch's current stream) and logged with its
+# algorithmic work (flops for the GEMM, bytes for the memory-bound kernels).
+PROFILE = None
+
+
+class _Prof:
+    __slots__ = ('name', 'work', 'e0')
+
+    def __init__(self, name, work):
+        self.name, self.work, self.e0 = name, work, None
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if self.e0 is not None and PROFILE is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            PROFILE.setdefault(self.name, []).append((self.e0, e1, self.work))
+
+
+def aggregate_bytes(V, E, H, backward=False):
+    """Algorithmic bytes of one GINE aggregation: per directed edge one neighbour row (4H),
+    its int32 column index and 1-byte bond class; per node its own row in, the output row out
+    and an int32 row pointer; the backward also reads the saved input row."""
+    return E * (4 * H + 5) + V * (8 * H + 4) + (V * 4 * H if backward else 0)
+
+
+def roofline_report(prof, hbm_peak_gbs, mfma_peak_tflops):
+    """Summarise a PROFILE dict (call after a device synchronise)."""
+    torch.cuda.synchronize()
+    groups = {}
+    for name, items in prof.items():
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in items)
+        groups[name] = {'launches': len(items), 'ms': ms, 'work': sum(w for _, _, w in items)}
+    out = {}
+
+    def entry(name, bound):
+        g = groups.get(name)
+        if not g or g['ms'] <= 0:
+            return None
+        if bound == 'mfma':
+            ach, peak, unit = g['work'] / (g['ms'] * 1e-3) / 1e12, mfma_peak_tflops, 'TFLOP/s'
+        else:
+            ach, peak, unit = g['work'] / (g['ms'] * 1e-3) / 1e9, hbm_peak_gbs, 'GB/s'
+        return {'kernel': name, 'bound': bound, 'achieved': round(ach, 2), 'peak': peak, 'unit': unit,
+                'frac': round(ach / peak, 4), 'traffic': None, 'launches': g['launches'],
+                'avg_launch_us': round(g['ms'] * 1e3 / g['launches'], 2),
+                'work_per_launch': round(g['work'] / g['launches'], 1)}
+
+    mf = entry('gemm_f32_kernel', 'mfma')
+    hb = entry('gine_aggregate_fwd_kernel', 'hbm')
+    hbb = entry('gine_aggregate_bwd_kernel', 'hbm')
+    cands = [e for e in (mf, hb, hbb) if e]
+    if cands:
+        dominant = max(cands, key=lambda e: groups[e['kernel']]['ms'])
+        out['roofline'] = dominant
+    if mf:
+        out['roofline_mfma'] = mf
+    if hb:
+        out['roofline_hbm'] = hb
+    if hbb:
+        out['roofline_hbm_bwd'] = hbb
+    out['event_ms_total'] = {k: round(v['ms'], 3) for k, v in sorted(groups.items())}
+    return out
+
+
 # --------------------------------------------------------------------------- raw calls
 def gemm(M, N, K, A, sa_m, sa_k, B, sb_k, sb_n, C, ldc, bias=None, relu=False, accumulate=False,
          amask=None, split_k=0):
     L = lib()
     nbytes = L.psvae_gemm_f32_workspace_bytes(M, N, K, split_k)
     ws = workspace(nbytes, C.device) if nbytes else None
-    rc = L.psvae_gemm_f32(M, N, K, ptr(A, torch.float32), ptr(amask, torch.float32), sa_m, sa_k,
-                          ptr(B, torch.float32), sb_k, sb_n, ptr(C, torch.float32), ldc,
-                          ptr(bias, torch.float32), 1 if relu else 0, 1 if accumulate else 0, split_k,
-                          ptr(ws), nbytes, _stream())
+    with _Prof('gemm_f32_kernel', 2.0 * M * N * K):
+        rc = L.psvae_gemm_f32(M, N, K, ptr(A, torch.float32), ptr(amask, torch.float32), sa_m, sa_k,
+                              ptr(B, torch.float32), sb_k, sb_n, ptr(C, torch.float32), ldc,
+                              ptr(bias, torch.float32), 1 if relu else 0, 1 if accumulate else 0, split_k,
+                              ptr(ws), nbytes, _stream())
     _check(rc, 'psvae_gemm_f32')
 
 
@@ -141,9 +213,11 @@ def gine_aggregate_fwd(x, table, row_ptr, col, cls, out):
     V, H = x.shape
     px, ldx = _rows(x)
     po, ldo = _rows(out)
-    _check(lib().psvae_gine_aggregate_fwd(V, H, table.shape[0], px, ldx, ptr(table, torch.float32),
-                                          ptr(row_ptr, torch.int32), ptr(col, torch.int32), ptr(cls, torch.uint8),
-                                          po, ldo, _stream()), 'psvae_gine_aggregate_fwd')
+    with _Prof('gine_aggregate_fwd_kernel', aggregate_bytes(V, col.numel(), H)):
+        rc = lib().psvae_gine_aggregate_fwd(V, H, table.shape[0], px, ldx, ptr(table, torch.float32),
+                                            ptr(row_ptr, torch.int32), ptr(col, torch.int32),
+                                            ptr(cls, torch.uint8), po, ldo, _stream())
+    _check(rc, 'psvae_gine_aggregate_fwd')
 
 
 def gine_aggregate_bwd(x, table, g, t_row_ptr, t_col, t_cls, g_x, g_table):
@@ -155,10 +229,12 @@ def gine_aggregate_bwd(x, table, g, t_row_ptr, t_col, t_cls, g_x, g_table):
     pgx, ldgx = _rows(g_x)
     nbytes = L.psvae_gine_aggregate_bwd_workspace_bytes(V, H, C)
     ws = workspace(nbytes, x.device) if nbytes else None
-    _check(L.psvae_gine_aggregate_bwd(V, H, C, px, ldx, ptr(table, torch.float32), pg, ldg,
-                                      ptr(t_row_ptr, torch.int32), ptr(t_col, torch.int32), ptr(t_cls, torch.uint8),
-                                      pgx, ldgx, ptr(g_table, torch.float32), ptr(ws), nbytes, _stream()),
-           'psvae_gine_aggregate_bwd')
+    with _Prof('gine_aggregate_bwd_kernel', aggregate_bytes(V, t_col.numel(), H, backward=True)):
+        rc = L.psvae_gine_aggregate_bwd(V, H, C, px, ldx, ptr(table, torch.float32), pg, ldg,
+                                        ptr(t_row_ptr, torch.int32), ptr(t_col, torch.int32),
+                                        ptr(t_cls, torch.uint8), pgx, ldgx, ptr(g_table, torch.float32),
+                                        ptr(ws), nbytes, _stream())
+    _check(rc, 'psvae_gine_aggregate_bwd')
 
 
 def embed_atom_fwd(x, xp, xq, ea, ep, eq, out):

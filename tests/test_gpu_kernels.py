@@ -393,7 +393,7 @@ def test_collate_batch_512_vs_oracle(tokenizer):
     from ps_vae_amd.data.synthetic import synthetic_step1
     step1 = synthetic_step1(512, seed=77, shape='zinc')
     rng = np.random.default_rng(5)
-    uniforms = rng.random(400 * 512)
+    uniforms = rng.random(700 * 512)
     want, used = collate_ref.collate(step1, uniforms, piece_pad=tokenizer.pad_idx())
     check_collate(step1, uniforms[:used], want, tokenizer)
 

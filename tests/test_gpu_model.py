@@ -121,17 +121,32 @@ def test_default_width_model_against_reference_golden(tokenizer):
 
 def test_default_width_batch_256_against_oracle(tokenizer):
     """A larger batch through the compact path vs the CPU oracle on the reference layout of
-    the same collation: every loss and every parameter gradient."""
+    the same collation: every loss and every parameter gradient.
+
+    Yardstick: the oracle evaluated in float64.  Two fp32 implementations that sum in
+    different orders cannot agree to 1e-5 on every gradient of a network this deep (the fp32
+    CPU oracle itself is off the float64 result by up to ~3e-3 of the tensor's largest entry
+    on decoder.piece_embedding.weight), so each gradient must be within 1e-5 relative of the
+    float64 value OR at least as close to it as twice the fp32 CPU oracle's own distance.
+
+    ReLU kinks: with ~16 M ReLU inputs in this batch a few lie within fp32 rounding of zero,
+    and an implementation that rounds differently takes the other side of the kink (the loss
+    is not differentiable there).  The test counts the ReLU outputs whose sign differs from
+    the float64 oracle's; they must be at most 8, and only when there is such a flip is the
+    bound on the gradients relaxed to 2e-3 of the tensor's largest entry."""
+    import copy
+    import ps_vae_amd.modules.common_nn as common_nn
     from ps_vae_amd.data.collate import collate_packed
     from ps_vae_amd.data.packed import PackedMolecules
     from ps_vae_amd.data.synthetic import synthetic_step1
     B = 256
     step1 = synthetic_step1(B, seed=123, shape='zinc')
-    uniforms = np.random.default_rng(1).random(500 * B)
+    uniforms = np.random.default_rng(1).random(700 * B)
     want_batch, used = collate_ref.collate(step1, uniforms, piece_pad=tokenizer.pad_idx())
     cfg = model_ref.default_config(tokenizer)
     torch.manual_seed(7)
     ref = model_ref.PSVAEModel(cfg, tokenizer)
+    ref64 = copy.deepcopy(ref).double()
     model, _ = hip_model(tokenizer, state=ref.state_dict())
     eps = torch.randn(B, 56, generator=torch.Generator().manual_seed(2))
     tb = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in want_batch.items()}
@@ -139,22 +154,55 @@ def test_default_width_batch_256_against_oracle(tokenizer):
     ref_loss = ref.weighted_loss(pl, rec, kl)
     ref_loss.backward()
 
+    relu64 = []      # float64 ReLU outputs in call order, real atoms / pairs only
+    real = ~tb['atom_mask'].flatten()
+
+    def rec_relu(mod, inp, out):
+        relu64.append(out.detach()[real] if out.shape[0] == real.numel() else out.detach())
+    hooks = [m.register_forward_hook(rec_relu) for m in ref64.modules() if isinstance(m, torch.nn.ReLU)]
+    pl64, (rec64, piece64, edge64, kl64) = ref64(tb, eps.double())
+    for h in hooks:
+        h.remove()
+    ref64.weighted_loss(pl64, rec64, kl64).backward()
+
     packed = PackedMolecules.from_step1(step1)
     batch = collate_packed(packed.to_device(dev()), np.arange(B), uniforms=torch.from_numpy(uniforms).to(dev()),
                            atom_pad=tokenizer.atom_pad_idx(), piece_pad=tokenizer.pad_idx(), reference_layout=False)
     assert batch.num_uniforms == used
-    gpl, (grec, gpiece, gedge, gkl) = model(batch, eps=eps.to(dev()))
+    common_nn.TRACE = []
+    try:
+        gpl, (grec, gpiece, gedge, gkl) = model(batch, eps=eps.to(dev()))
+        relu_gpu = [out for _, relu, out in common_nn.TRACE if relu]
+    finally:
+        common_nn.TRACE = None
     loss = model.weighted_loss(gpl, grec, gkl)
     loss.backward()
     for name, a, b in [('total', loss, ref_loss), ('pred', gpl, pl), ('piece', gpiece, piece), ('edge', gedge, edge),
                        ('kl', gkl, kl)]:
         np.testing.assert_allclose(a.item(), b.item(), rtol=1e-5, err_msg=name)
-    refp = dict(ref.named_parameters())
+
+    # the oracle calls its ReLU modules in the same order as the HIP model runs its fused
+    # Linear+ReLU layers: encoder x4, decoder GNN x4, link MLP x2, predictor x2
+    assert len(relu_gpu) == len(relu64)
+    flips = 0
+    for a, b in zip(relu_gpu, relu64):
+        assert a.shape == b.shape
+        flips += ((a.cpu() > 0) != (b > 0)).sum().item()
+    assert flips <= 8, f'{flips} ReLU outputs on the other side of the kink'
+    kink_bound = 2e-3 if flips else 0.0
+
+    refp, refp64 = dict(ref.named_parameters()), dict(ref64.named_parameters())
     for k, p in model.named_parameters():
         if refp[k].grad is None:
             assert p.grad is None, k
             continue
-        close(p.grad, refp[k].grad, rel=3e-5, what=f'grad {k}')
+        g64 = refp64[k].grad
+        scale = g64.abs().max().item()
+        err_gpu = (p.grad.cpu().double() - g64).abs().max().item()
+        err_cpu = (refp[k].grad.double() - g64).abs().max().item()
+        assert err_gpu <= max(1e-5 * scale, 2.0 * err_cpu, kink_bound * scale), \
+            f'grad {k}: GPU {err_gpu / scale:.2e}, fp32 CPU oracle {err_cpu / scale:.2e} (relative to float64), ' \
+            f'{flips} ReLU flips'
 
 
 def test_infer_links_against_reference_golden(tokenizer):
