@@ -151,7 +151,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     prof, hip.PROFILE = hip.PROFILE, None
-    final_loss = float(model.logged['reconstruct loss'])
+    final_loss = float(model.logged['reconstruct loss'].detach())
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
