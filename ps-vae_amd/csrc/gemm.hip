@@ -1,45 +1,63 @@
 // f32 matrix products on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32).
 //
-// One kernel serves the three products of a Linear layer (reference:
+// One entry point serves the three products of a Linear layer (reference:
 // src/modules/common_nn.py:8-23 and its autograd): operands are addressed through element
 // strides, so X W^T, dY W and dY^T X differ only in the strides passed.  The MFMA is an exact
 // f32 fused-multiply-add chain in k order, so results match a plain f32 dot product to
 // rounding of the summation order.
 //
-// Tiling: 256 threads = 4 waves (64 lanes each) per workgroup, BK = 32.  Tiles are staged in
-// LDS k-major (T[k][x], row stride BX+1) so that an MFMA operand fetch is one conflict-free
-// ds_read_b32 per lane (lanes 0-31 read consecutive x at k, lanes 32-63 at k+1 — exactly the
-// 32x32x2 operand layout).  The next tile's global loads are issued before the current
-// tile's MFMAs (register prefetch).  Workgroups that share an A row-panel are placed on one
-// XCD (blockIdx % 8) so the panel is fetched into one L2 only.
+// Two kernels:
+//  * gemm_panel_kernel<TN, BK, A_KC, B_KC> — the fast path.  A workgroup (4 waves of 64 lanes)
+//    owns a 128-row panel of C and ALL its columns (or half of them when N > 352): wave w
+//    holds rows 32w..32w+31 x 32*TN columns in TN accumulator tiles.  The layer widths of
+//    this model (200, 300, 328, 400, 656, 56, 302) fit 32*TN with < 7 % padding, the A panel
+//    is read from HBM exactly once, and per k-step a wave issues TN MFMAs for TN+1 LDS reads.
+//    Global loads are 16 B per lane and the next k-tile is in flight (registers) while the
+//    current one is multiplied.  Needs 16-byte aligned operands (checked on the host).
+//  * gemm_generic_kernel — any strides / alignment, 64x64 tiles, scalar loads.
+//
+// LDS tiles are k-major (T[k][x]): an MFMA operand fetch is one conflict-free ds_read_b32 per
+// lane (lanes 0-31 read consecutive x at k, lanes 32-63 at k+1 — the 32x32x2 operand layout).
+// Row strides are chosen per loader so the staging stores are conflict-free too.
+// Workgroups that share an A row-panel sit on one XCD (blockIdx % 8).
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int BK = 32;
 constexpr int THREADS = 256;
 
 struct GemmArgs {
     int M, N, K;
+    int n_ext;            // N + 1 when rowsum is requested (a virtual all-ones column of B)
     const float *A;
-    const float *amask;   // optional, same strides as A: A(m,k) counts as 0 where amask(m,k) <= 0
+    const float *amask;   // optional, addressed like A: A(m,k) counts as 0 where amask(m,k) <= 0
     long long sa_m, sa_k;
     const float *B;
     long long sb_k, sb_n;
     float *C;
     long long ldc;
     const float *bias;
+    float *rowsum;        // optional [M]: sum_k A(m,k)
     int act;
     int accumulate;
     int split_k;
-    int k_chunk;     // multiple of BK
-    float *ws;       // [split_k][M][N] when split_k > 1
-    int nt_m, nt_n;
+    int k_chunk;          // multiple of 32
+    float *ws;            // [split_k][M][ws_ld] when split_k > 1
+    int ws_ld;            // n_ext rounded up to a multiple of 4
+    int c_vec;            // C (and ws) rows may be written 16 bytes at a time
+    int nt_m, nt_n, bn;   // tiles and column-tile width
 };
 
 __device__ __forceinline__ void epilogue_store(const GemmArgs &g, int row, int col, float v) {
+    if (col == g.N) {   // the virtual ones column: row sums of A
+        float *r = g.rowsum + row;
+        *r = g.accumulate ? *r + v : v;
+        return;
+    }
     if (g.bias) v += g.bias[col];
     if (g.act == PSVAE_ACT_RELU) v = fmaxf(v, 0.f);
     float *c = g.C + (long long)row * g.ldc + col;
@@ -47,182 +65,428 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs &g, int row, int c
     *c = v;
 }
 
-// Global -> registers for one BK x BX tile of a strided operand; element (x, k) lives at
-// p[x*sx + k*sk].  KCONTIG: lanes run along k (coalesced when sk == 1); otherwise along x.
-// `pm` (optional) gates the element: it counts as 0 where pm[same offset] <= 0 (the ReLU
-// derivative applied to a gradient operand while it is loaded).
-template <int BX, bool KCONTIG>
-__device__ __forceinline__ void load_tile(float (&r)[BX / 8], const float *__restrict__ p,
-                                          const float *__restrict__ pm, long long sx, long long sk, int x0,
-                                          int k0, int X, int k_end, int tid) {
-    if (KCONTIG) {
-        const int k = k0 + (tid & 31), xr = x0 + (tid >> 5);
-        const bool kok = k < k_end;
-#pragma unroll
-        for (int i = 0; i < BX / 8; ++i) {
-            const int x = xr + 8 * i;
-            const long long off = (long long)x * sx + (long long)k * sk;
-            float v = (kok && x < X) ? p[off] : 0.f;
-            if (pm != nullptr && kok && x < X && !(pm[off] > 0.f)) v = 0.f;
-            r[i] = v;
-        }
-    } else {
-        constexpr int KS = THREADS / BX;
-        const int x = x0 + (tid % BX), kb = k0 + (tid / BX);
-        const bool xok = x < X;
-#pragma unroll
-        for (int i = 0; i < BX / 8; ++i) {
-            const int k = kb + KS * i;
-            const long long off = (long long)x * sx + (long long)k * sk;
-            float v = (xok && k < k_end) ? p[off] : 0.f;
-            if (pm != nullptr && xok && k < k_end && !(pm[off] > 0.f)) v = 0.f;
-            r[i] = v;
-        }
-    }
+__device__ __forceinline__ void store_result(const GemmArgs &g, int z, int row, int col, float v) {
+    if (g.split_k > 1)
+        g.ws[((long long)z * g.M + row) * g.ws_ld + col] = v;
+    else
+        epilogue_store(g, row, col, v);
 }
 
-template <int BX, bool KCONTIG>
-__device__ __forceinline__ void store_tile(float (*T)[BX + 1], const float (&r)[BX / 8], int tid) {
-    if (KCONTIG) {
-        const int k = tid & 31, xr = tid >> 5;
-#pragma unroll
-        for (int i = 0; i < BX / 8; ++i) T[k][xr + 8 * i] = r[i];
-    } else {
-        constexpr int KS = THREADS / BX;
-        const int x = tid % BX, kb = tid / BX;
-#pragma unroll
-        for (int i = 0; i < BX / 8; ++i) T[kb + KS * i][x] = r[i];
-    }
-}
-
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool A_KC, bool B_KC>
-__global__ __launch_bounds__(THREADS) void gemm_f32_kernel(GemmArgs g) {
-    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
-    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
-    constexpr int TM = WM / 32, TN = WN / 32;
-    __shared__ float As[BK][BM + 1];
-    __shared__ float Bs[BK][BN + 1];
-
-    // XCD-aware tile assignment: the nt_n column tiles of one row panel get consecutive
-    // local ids on one XCD.
+// XCD-aware work assignment on a 1-D grid.  A unit = (row panel, K split); its nt_n column
+// tiles get consecutive local ids on one XCD (blockIdx % 8 picks the XCD), so the A panel
+// chunk they share is fetched into one L2, and the units are dealt round-robin over the
+// XCDs so that a product with few row panels but many splits still fills the whole chip.
+// Returns false for the padding blocks of the last group of 8 units.
+__device__ __forceinline__ bool tile_of_block(const GemmArgs &g, int &tile_m, int &tile_n, int &z) {
     const int bid = blockIdx.x;
     const int xcd = bid & 7, local = bid >> 3;
-    const int tile_n = local % g.nt_n;
-    const int tile_m = (local / g.nt_n) * 8 + xcd;
-    if (tile_m >= g.nt_m) return;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int z = blockIdx.y;
-    const int k_begin = z * g.k_chunk;
-    const int k_end = min(g.K, k_begin + g.k_chunk);
+    tile_n = local % g.nt_n;
+    const int unit = (local / g.nt_n) * 8 + xcd;
+    tile_m = unit % g.nt_m;
+    z = unit / g.nt_m;
+    return z < g.split_k;
+}
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int l31 = lane & 31, lhi = lane >> 5;
+// ------------------------------------------------------------------------------------------
+// Fast path: 128 x (32*TN) panel per workgroup, vector loads.
+// ------------------------------------------------------------------------------------------
+template <int BX, int BK, bool KCONTIG>
+struct TileLoader {
+    static constexpr int ITEMS = BX * BK / 4;                         // float4 items per tile
+    static constexpr int PER_THREAD = (ITEMS + THREADS - 1) / THREADS;
+    static constexpr int STRIDE = KCONTIG ? BX + 1 : BX + 4;          // LDS row stride (floats)
 
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    float ra[BM / 8], rb[BN / 8];
-    if (k_begin < k_end) {
-        load_tile<BM, A_KC>(ra, g.A, g.amask, g.sa_m, g.sa_k, m0, k_begin, g.M, k_end, tid);
-        load_tile<BN, B_KC>(rb, g.B, nullptr, g.sb_n, g.sb_k, n0, k_begin, g.N, k_end, tid);
-    }
-    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
-        store_tile<BM, A_KC>(As, ra, tid);
-        store_tile<BN, B_KC>(Bs, rb, tid);
-        __syncthreads();
-        if (k0 + BK < k_end) {
-            load_tile<BM, A_KC>(ra, g.A, g.amask, g.sa_m, g.sa_k, m0, k0 + BK, g.M, k_end, tid);
-            load_tile<BN, B_KC>(rb, g.B, nullptr, g.sb_n, g.sb_k, n0, k0 + BK, g.N, k_end, tid);
+    // element (x, k) of the operand lives at p[x*sx + k*sk]; KCONTIG: sk == 1, else sx == 1.
+    // MASK: the element counts as 0 where pm[same offset] <= 0.  ONES: a virtual column of
+    // ones at x == ones_x (only for !KCONTIG).
+    //
+    // load() ONLY issues the global loads (unconditionally, from a clamped address) and
+    // store() applies bounds / mask / ones while writing LDS one k-tile later.  Anything that
+    // consumes a loaded value before the MFMA loop — or a branch around a load — makes the
+    // compiler wait for the loads right there and the prefetch no longer overlaps the MFMAs.
+    struct Coord {
+        int x, k;
+        bool in_tile;
+    };
+    __device__ static __forceinline__ Coord coord(int i, int tid, int x0, int k0) {
+        const int item = tid + THREADS * i;
+        Coord c;
+        if (KCONTIG) {
+            c.x = x0 + item / (BK / 4), c.k = k0 + 4 * (item % (BK / 4));
+        } else {
+            c.x = x0 + 4 * (item % (BX / 4)), c.k = k0 + item / (BX / 4);
         }
-#pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            float a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = As[kk + lhi][wm * WM + i * 32 + l31];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Bs[kk + lhi][wn * WN + j * 32 + l31];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-        __syncthreads();
+        c.in_tile = (ITEMS % THREADS == 0) || item < ITEMS;
+        return c;
     }
 
-    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+    template <bool MASK>
+    __device__ static __forceinline__ void load(float4 (&r)[PER_THREAD], float4 (&rm)[MASK ? PER_THREAD : 1],
+                                                const float *__restrict__ p, const float *__restrict__ pm,
+                                                long long sx, long long sk, int x0, int k0, int X, int k_end,
+                                                int tid) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < PER_THREAD; ++i) {
+            const Coord c = coord(i, tid, x0, k0);
+            const bool ok = c.in_tile && c.x < X && c.k < k_end;
+            const long long off = ok ? (KCONTIG ? (long long)c.x * sx + c.k : (long long)c.k * sk + c.x) : 0;
+            r[i] = *reinterpret_cast<const float4 *>(p + off);
+            if (MASK) rm[i] = *reinterpret_cast<const float4 *>(pm + off);
+        }
+    }
+
+    template <bool MASK, bool ONES>
+    __device__ static __forceinline__ void store(float *T, const float4 (&r)[PER_THREAD],
+                                                 const float4 (&rm)[MASK ? PER_THREAD : 1], int x0, int k0, int X,
+                                                 int k_end, int ones_x, int tid) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn * WN + j * 32 + l31;
-            if (col >= g.N) continue;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                if (row >= g.M) continue;
-                if (g.split_k > 1)
-                    g.ws[((long long)z * g.M + row) * g.N + col] = acc[i][j][r];
-                else
-                    epilogue_store(g, row, col, acc[i][j][r]);
+        for (int i = 0; i < PER_THREAD; ++i) {
+            const Coord c = coord(i, tid, x0, k0);
+            if (!c.in_tile) continue;
+            const bool ok = c.x < X && c.k < k_end;
+            float4 v = r[i];
+            if (MASK) {
+                const float4 m = rm[i];
+                v.x = m.x > 0.f ? v.x : 0.f, v.y = m.y > 0.f ? v.y : 0.f;
+                v.z = m.z > 0.f ? v.z : 0.f, v.w = m.w > 0.f ? v.w : 0.f;
+            }
+            v.x = ok ? v.x : 0.f, v.y = ok ? v.y : 0.f, v.z = ok ? v.z : 0.f, v.w = ok ? v.w : 0.f;
+            if (ONES && !KCONTIG) v.x = (c.k < k_end && c.x == ones_x) ? 1.f : v.x;
+            const int item = tid + THREADS * i;
+            if (KCONTIG) {
+                const int kq = item % (BK / 4), x = item / (BK / 4);
+                float *d = T + (4 * kq) * STRIDE + x;
+                d[0] = v.x, d[STRIDE] = v.y, d[2 * STRIDE] = v.z, d[3 * STRIDE] = v.w;
+            } else {
+                const int xq = item % (BX / 4), k = item / (BX / 4);
+                *reinterpret_cast<float4 *>(T + k * STRIDE + 4 * xq) = v;
             }
         }
+    }
+};
+
+template <int TN, int BK, bool A_KC, bool B_KC, bool MASK, bool ONES>
+__global__ __launch_bounds__(THREADS, 2) void gemm_panel_kernel(GemmArgs g) {
+    constexpr int BM = 128, BN = 32 * TN;
+    using LA = TileLoader<BM, BK, A_KC>;
+    using LB = TileLoader<BN, BK, B_KC>;
+    constexpr int A_FLOATS = BK * LA::STRIDE, B_FLOATS = BK * LB::STRIDE;
+    constexpr int EPI_STRIDE = 36, EPI_FLOATS = 4 * 32 * EPI_STRIDE;   // one 32x32 tile per wave
+    constexpr int LDS_FLOATS = A_FLOATS + B_FLOATS > EPI_FLOATS ? A_FLOATS + B_FLOATS : EPI_FLOATS;
+    __shared__ __align__(16) float smem[LDS_FLOATS];
+    float *As = smem, *Bs = smem + A_FLOATS;
+
+    int tile_m, tile_n, z;
+    if (!tile_of_block(g, tile_m, tile_n, z)) return;
+    const int m0 = tile_m * BM, n0 = tile_n * g.bn;
+    const int k_begin = z * g.k_chunk;
+    const int k_end = min(g.K, k_begin + g.k_chunk);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int ones_x = g.N;
+    const int n_lim = min(g.N, n0 + g.bn);   // columns of B this tile may read
+
+    f32x16 acc[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    float4 ra[LA::PER_THREAD], rb[LB::PER_THREAD], rma[MASK ? LA::PER_THREAD : 1], rmb[1];
+    if (k_begin < k_end) {
+        LA::template load<MASK>(ra, rma, g.A, g.amask, g.sa_m, g.sa_k, m0, k_begin, g.M, k_end, tid);
+        LB::template load<false>(rb, rmb, g.B, nullptr, g.sb_n, g.sb_k, n0, k_begin, n_lim, k_end, tid);
+    }
+    const float *a_rd = As + lhi * LA::STRIDE + wave * 32 + l31;
+    const float *b_rd = Bs + lhi * LB::STRIDE + l31;
+    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+#ifdef PSVAE_EXP_NOSTORE   // timing experiment only: wrong results
+        if (k0 == k_begin) {
+#endif
+        LA::template store<MASK, false>(As, ra, rma, m0, k0, g.M, k_end, -1, tid);
+        LB::template store<false, ONES>(Bs, rb, rmb, n0, k0, n_lim, k_end, ones_x, tid);
+        __syncthreads();
+#ifdef PSVAE_EXP_NOSTORE
+        }
+#endif
+#ifdef PSVAE_EXP_NOLOAD
+        if (false) {
+#else
+        if (k0 + BK < k_end) {
+#endif
+            LA::template load<MASK>(ra, rma, g.A, g.amask, g.sa_m, g.sa_k, m0, k0 + BK, g.M, k_end, tid);
+            LB::template load<false>(rb, rmb, g.B, nullptr, g.sb_n, g.sb_k, n0, k0 + BK, n_lim, k_end, tid);
+        }
+        // operand registers for k-step s+1 are fetched from LDS while the MFMAs of step s run;
+        // the scheduling barriers keep the compiler from sinking the reads next to their use
+        float a_cur = a_rd[0], b_cur[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b_cur[j] = b_rd[j * 32];
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float a_nxt = 0.f, b_nxt[TN];
+            if (kk + 2 < BK) {
+                a_nxt = a_rd[(kk + 2) * LA::STRIDE];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b_nxt[j] = b_rd[(kk + 2) * LB::STRIDE + j * 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur[j], acc[j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk + 2 < BK) {
+                a_cur = a_nxt;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b_cur[j] = b_nxt[j];
+            }
+        }
+#ifndef PSVAE_EXP_NOSTORE
+        __syncthreads();
+#endif
+    }
+
+    // Epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) +
+    // 4 * (lane >> 5): a direct store would be 16 dword stores per tile, each touching two
+    // 128-B row segments.  Instead every wave transposes one tile at a time through its own
+    // 32 x 36 LDS patch and writes float4 per lane: 4 store instructions of 8 rows x 128 B.
+    const int col_lim = min(g.n_ext, n0 + g.bn);
+    const bool split = g.split_k > 1;
+    float *out = split ? g.ws + (long long)z * g.M * g.ws_ld : g.C;
+    const long long ld = split ? g.ws_ld : g.ldc;
+    if (g.c_vec) {
+        float *patch = smem + wave * 32 * EPI_STRIDE;
+        const int prow = lane >> 3, pc4 = (lane & 7) * 4;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int cbase = n0 + j * 32;
+            if (cbase >= col_lim) continue;   // wave-uniform
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                patch[((r & 3) + 8 * (r >> 2) + 4 * lhi) * EPI_STRIDE + l31] = acc[j][r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int col = cbase + pc4;
+            float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!split && g.bias && col < g.N) bias4 = *reinterpret_cast<const float4 *>(g.bias + col);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = m0 + wave * 32 + prow + 8 * i;
+                float4 v = *reinterpret_cast<const float4 *>(patch + (prow + 8 * i) * EPI_STRIDE + pc4);
+#ifdef PSVAE_EXP_NOEPI   // timing experiment only
+                if (v.x != 12345.678f) continue;
+#endif
+                if (row >= g.M || col >= col_lim) continue;
+                if (split) {
+                    *reinterpret_cast<float4 *>(out + (long long)row * ld + col) = v;
+                } else if (col == g.N) {          // the virtual ones column (N % 4 == 0 here)
+                    float *rs = g.rowsum + row;
+                    *rs = g.accumulate ? *rs + v.x : v.x;
+                } else {
+                    v.x += bias4.x, v.y += bias4.y, v.z += bias4.z, v.w += bias4.w;
+                    if (g.act == PSVAE_ACT_RELU)
+                        v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+                    float4 *dst = reinterpret_cast<float4 *>(out + (long long)row * ld + col);
+                    if (g.accumulate) {
+                        const float4 o = *dst;
+                        v.x += o.x, v.y += o.y, v.z += o.z, v.w += o.w;
+                    }
+                    *dst = v;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // patch is rewritten by the next tile
+        }
+    } else {
+        const int row0 = m0 + wave * 32 + 4 * lhi;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + j * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + (r & 3) + 8 * (r >> 2);
+                if (col < col_lim && row < g.M) store_result(g, z, row, col, acc[j][r]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Generic path: 64 x 64 tiles, scalar loads, any strides.
+// ------------------------------------------------------------------------------------------
+constexpr int GBK = 32, GB = 64;
+
+template <bool KCONTIG>
+__device__ __forceinline__ void generic_load(float (&r)[GB / 8], const float *__restrict__ p,
+                                             const float *__restrict__ pm, long long sx, long long sk, int x0,
+                                             int k0, int X, int k_end, int ones_x, int tid) {
+#pragma unroll
+    for (int i = 0; i < GB / 8; ++i) {
+        int x, k;
+        if (KCONTIG) {
+            k = k0 + (tid & 31), x = x0 + (tid >> 5) + 8 * i;
+        } else {
+            x = x0 + (tid % GB), k = k0 + (tid / GB) + (THREADS / GB) * i;
+        }
+        float v = 0.f;
+        if (k < k_end) {
+            if (x < X) {
+                const long long off = (long long)x * sx + (long long)k * sk;
+                v = p[off];
+                if (pm != nullptr && !(pm[off] > 0.f)) v = 0.f;
+            } else if (x == ones_x) {
+                v = 1.f;
+            }
+        }
+        r[i] = v;
+    }
+}
+
+template <bool KCONTIG>
+__device__ __forceinline__ void generic_store(float (*T)[GB + 1], const float (&r)[GB / 8], int tid) {
+#pragma unroll
+    for (int i = 0; i < GB / 8; ++i) {
+        if (KCONTIG)
+            T[tid & 31][(tid >> 5) + 8 * i] = r[i];
+        else
+            T[(tid / GB) + (THREADS / GB) * i][tid % GB] = r[i];
+    }
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(THREADS) void gemm_generic_kernel(GemmArgs g) {
+    __shared__ float As[GBK][GB + 1];
+    __shared__ float Bs[GBK][GB + 1];
+    int tile_m, tile_n, z;
+    if (!tile_of_block(g, tile_m, tile_n, z)) return;
+    const int m0 = tile_m * GB, n0 = tile_n * GB;
+    const int k_begin = z * g.k_chunk;
+    const int k_end = min(g.K, k_begin + g.k_chunk);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int ones_x = g.rowsum ? g.N : -1;
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float ra[GB / 8], rb[GB / 8];
+    if (k_begin < k_end) {
+        generic_load<A_KC>(ra, g.A, g.amask, g.sa_m, g.sa_k, m0, k_begin, g.M, k_end, -1, tid);
+        generic_load<B_KC>(rb, g.B, nullptr, g.sb_n, g.sb_k, n0, k_begin, g.N, k_end, ones_x, tid);
+    }
+    for (int k0 = k_begin; k0 < k_end; k0 += GBK) {
+        generic_store<A_KC>(As, ra, tid);
+        generic_store<B_KC>(Bs, rb, tid);
+        __syncthreads();
+        if (k0 + GBK < k_end) {
+            generic_load<A_KC>(ra, g.A, g.amask, g.sa_m, g.sa_k, m0, k0 + GBK, g.M, k_end, -1, tid);
+            generic_load<B_KC>(rb, g.B, nullptr, g.sb_n, g.sb_k, n0, k0 + GBK, g.N, k_end, ones_x, tid);
+        }
+#pragma unroll
+        for (int kk = 0; kk < GBK; kk += 2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[kk + lhi][wm * 32 + l31], Bs[kk + lhi][wn * 32 + l31], acc,
+                                                       0, 0, 0);
+        __syncthreads();
+    }
+    const int col = n0 + wn * 32 + l31;
+    if (col >= g.n_ext) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        if (row < g.M) store_result(g, z, row, col, acc[r]);
+    }
 }
 
 // Sum the split-K slabs in slab order and apply the epilogue.
 __global__ void gemm_splitk_reduce_kernel(GemmArgs g) {
-    const long long total = (long long)g.M * g.N;
+    const long long total = (long long)g.M * g.ws_ld;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
+        const int row = (int)(idx / g.ws_ld), col = (int)(idx % g.ws_ld);
+        if (col >= g.n_ext) continue;
         float v = 0.f;
         for (int z = 0; z < g.split_k; ++z) v += g.ws[(long long)z * total + idx];
-        epilogue_store(g, (int)(idx / g.N), (int)(idx % g.N), v);
+        epilogue_store(g, row, col, v);
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
-void launch_cfg(const GemmArgs &g, bool a_kc, bool b_kc, dim3 grid, hipStream_t s) {
-    if (a_kc && b_kc)
-        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WAVES_M, WAVES_N, true, true>), grid, dim3(THREADS), 0, s, g);
-    else if (a_kc)
-        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WAVES_M, WAVES_N, true, false>), grid, dim3(THREADS), 0, s, g);
-    else if (b_kc)
-        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WAVES_M, WAVES_N, false, true>), grid, dim3(THREADS), 0, s, g);
-    else
-        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WAVES_M, WAVES_N, false, false>), grid, dim3(THREADS), 0, s, g);
+template <int TN, int BK>
+void launch_panel(const GemmArgs &g, bool a_kc, bool b_kc, dim3 grid, hipStream_t s) {
+    const bool mask = g.amask != nullptr, ones = g.rowsum != nullptr;
+    const dim3 blk(THREADS);
+#define PSVAE_PANEL(AKC, BKC, MASK, ONES) \
+    hipLaunchKernelGGL((gemm_panel_kernel<TN, BK, AKC, BKC, MASK, ONES>), grid, blk, 0, s, g)
+    if (a_kc && b_kc) {                 // forward X W^T
+        if (mask) PSVAE_PANEL(true, true, true, false); else PSVAE_PANEL(true, true, false, false);
+    } else if (a_kc) {                  // input gradient dY W
+        if (mask) PSVAE_PANEL(true, false, true, false); else PSVAE_PANEL(true, false, false, false);
+    } else if (b_kc) {
+        if (mask) PSVAE_PANEL(false, true, true, false); else PSVAE_PANEL(false, true, false, false);
+    } else {                            // weight (+ bias) gradient dY^T [X | 1]
+        if (mask && ones) PSVAE_PANEL(false, false, true, true);
+        else if (mask) PSVAE_PANEL(false, false, true, false);
+        else if (ones) PSVAE_PANEL(false, false, false, true);
+        else PSVAE_PANEL(false, false, false, false);
+    }
+#undef PSVAE_PANEL
 }
 
-}  // namespace
+// Widest column tile (a multiple of 32, at most 352 = 11 accumulator tiles per wave).
+// PSVAE_GEMM_MAX_BN overrides it for tuning runs.
+int panel_max_bn() {
+    static int v = 0;
+    if (v == 0) {
+        const char *e = getenv("PSVAE_GEMM_MAX_BN");
+        int x = e ? atoi(e) : 224;
+        v = x < 32 ? 32 : (x > 352 ? 352 : x / 32 * 32);
+    }
+    return v;
+}
 
-// split_k == 0: pick a split that fills the chip when the output has few tiles and K is long
-// (the weight-gradient products: M, N ~ 300, K = number of rows in the batch).
-static int resolve_split(int M, int N, int K, int split_k) {
+// Column tiling of the panel kernel: nc tiles of width bn (a multiple of 32), and the
+// instantiated TN that covers bn.
+void panel_shape(int n_ext, int &nc, int &bn, int &tn) {
+    nc = psvae_cdiv(n_ext, panel_max_bn());
+    bn = psvae_cdiv(psvae_cdiv(n_ext, nc), 32) * 32;
+    const int need = bn / 32;
+    static const int kTn[] = {1, 2, 3, 4, 5, 6, 7, 10, 11};
+    tn = 11;
+    for (int t : kTn)
+        if (t >= need) {
+            tn = t;
+            break;
+        }
+}
+
+// split_k == 0: pick a split that fills the chip when the output has few row panels and K is
+// long (the weight-gradient products: M, N ~ 300, K = number of rows in the batch).
+int resolve_split(int M, int N, int K, int split_k) {
     if (split_k >= 1) return split_k;
-    const long long tiles = (long long)psvae_cdiv(M, 64) * psvae_cdiv(N, 64);
-    if (tiles >= 256 || K <= 2048) return 1;
-    long long s = 1024 / tiles;
-    const long long by_k = K / 512;
+    int nc, bn, tn;
+    panel_shape(N + 1, nc, bn, tn);
+    const long long tiles = (long long)psvae_cdiv(M, 128) * nc;
+    if (tiles >= 192 || K <= 2048) return 1;
+    long long s = 512 / tiles;
+    const long long by_k = K / 256;
     if (s > by_k) s = by_k;
     return s < 1 ? 1 : (int)s;
 }
 
+bool vec_ok(const float *p, long long s_major) {
+    return p == nullptr || (psvae_aligned16(p) && s_major % 4 == 0);
+}
+
+}  // namespace
+
 extern "C" size_t psvae_gemm_f32_workspace_bytes(int M, int N, int K, int split_k) {
     split_k = resolve_split(M, N, K, split_k);
     if (split_k <= 1 || M <= 0 || N <= 0) return 0;
-    return (size_t)split_k * (size_t)M * (size_t)N * sizeof(float);
+    return (size_t)split_k * (size_t)M * (size_t)(N + 4) * sizeof(float);
 }
 
 extern "C" int psvae_gemm_f32(int M, int N, int K, const float *A, const float *amask, int64_t sa_m,
                               int64_t sa_k, const float *B, int64_t sb_k, int64_t sb_n, float *C, int64_t ldc,
-                              const float *bias, int act, int accumulate, int split_k, void *workspace,
-                              size_t workspace_bytes, void *stream) {
+                              const float *bias, float *rowsum, int act, int accumulate, int split_k,
+                              void *workspace, size_t workspace_bytes, void *stream) {
     PSVAE_REQUIRE(M >= 0 && N >= 0 && K >= 0, PSVAE_EINVAL, "psvae_gemm_f32: negative dimension");
     if (M == 0 || N == 0) return PSVAE_OK;
     PSVAE_REQUIRE(C != nullptr && (K == 0 || (A != nullptr && B != nullptr)), PSVAE_EINVAL,
@@ -230,8 +494,8 @@ extern "C" int psvae_gemm_f32(int M, int N, int K, const float *A, const float *
     PSVAE_REQUIRE(ldc >= N, PSVAE_EINVAL, "psvae_gemm_f32: ldc %lld < N %d", (long long)ldc, N);
     PSVAE_REQUIRE(act == PSVAE_ACT_NONE || act == PSVAE_ACT_RELU, PSVAE_EINVAL, "psvae_gemm_f32: bad act %d", act);
     split_k = resolve_split(M, N, K, split_k);
-    int k_chunk = psvae_cdiv(psvae_cdiv(K, split_k), BK) * BK;
-    if (k_chunk == 0) k_chunk = BK;
+    int k_chunk = psvae_cdiv(psvae_cdiv(K, split_k), 32) * 32;
+    if (k_chunk == 0) k_chunk = 32;
     split_k = K > 0 ? psvae_cdiv(K, k_chunk) : 1;
     PSVAE_REQUIRE(split_k <= 65535, PSVAE_ETOOLARGE, "psvae_gemm_f32: split_k %d too large", split_k);
     if (split_k > 1) {
@@ -239,36 +503,59 @@ extern "C" int psvae_gemm_f32(int M, int N, int K, const float *A, const float *
                       PSVAE_EWORKSPACE, "psvae_gemm_f32: workspace too small for split_k %d", split_k);
     }
     GemmArgs g;
-    g.M = M, g.N = N, g.K = K;
+    g.M = M, g.N = N, g.K = K, g.n_ext = N + (rowsum ? 1 : 0);
+    g.ws_ld = (g.n_ext + 3) / 4 * 4;
+    g.c_vec = (split_k > 1 ? psvae_aligned16(workspace) : (psvae_aligned16(C) && ldc % 4 == 0)) && N % 4 == 0 &&
+              (bias == nullptr || psvae_aligned16(bias));
     g.A = A, g.amask = amask, g.sa_m = sa_m, g.sa_k = sa_k;
     g.B = B, g.sb_k = sb_k, g.sb_n = sb_n;
-    g.C = C, g.ldc = ldc, g.bias = bias, g.act = act;
+    g.C = C, g.ldc = ldc, g.bias = bias, g.rowsum = rowsum, g.act = act;
     g.accumulate = accumulate, g.split_k = split_k, g.k_chunk = k_chunk, g.ws = (float *)workspace;
     const bool a_kc = (sa_k == 1), b_kc = (sb_k == 1);
-
-    // Tile shape with the least padded work; ties go to the larger tile.
-    const long long w0 = (long long)psvae_cdiv(M, 128) * 128 * psvae_cdiv(N, 128) * 128;
-    const long long w1 = (long long)psvae_cdiv(M, 128) * 128 * psvae_cdiv(N, 64) * 64;
-    const long long w2 = (long long)psvae_cdiv(M, 64) * 64 * psvae_cdiv(N, 64) * 64;
-    int cfg = 0;
-    long long best = w0;
-    if (w1 < best) cfg = 1, best = w1;
-    if (w2 < best) cfg = 2, best = w2;
-    const int bm = cfg == 2 ? 64 : 128, bn = cfg == 0 ? 128 : 64;
-    g.nt_m = psvae_cdiv(M, bm), g.nt_n = psvae_cdiv(N, bn);
-    const long long blocks = (long long)psvae_cdiv(g.nt_m, 8) * 8 * g.nt_n;
-    PSVAE_REQUIRE(blocks < (1ll << 31), PSVAE_ETOOLARGE, "psvae_gemm_f32: grid too large");
-    dim3 grid((unsigned)blocks, (unsigned)split_k);
     hipStream_t s = (hipStream_t)stream;
-    if (cfg == 0)
-        launch_cfg<128, 128, 2, 2>(g, a_kc, b_kc, grid, s);
-    else if (cfg == 1)
-        launch_cfg<128, 64, 2, 2>(g, a_kc, b_kc, grid, s);
-    else
-        launch_cfg<64, 64, 2, 2>(g, a_kc, b_kc, grid, s);
+
+    // The panel kernel needs unit stride along one axis of each operand, 16-byte aligned
+    // bases / major strides, and the vectorised extent to be a multiple of 4.
+    const bool a_vec = (a_kc ? (K % 4 == 0 && vec_ok(A, sa_m)) : (sa_m == 1 && M % 4 == 0 && vec_ok(A, sa_k))) &&
+                       (amask == nullptr || psvae_aligned16(amask));
+    const bool b_vec = b_kc ? (K % 4 == 0 && vec_ok(B, sb_n)) : (sb_n == 1 && N % 4 == 0 && vec_ok(B, sb_k));
+    const bool panel = a_vec && b_vec && (!rowsum || !b_kc) && M >= 32;
+
+    if (panel) {
+        int nc, bn, tn;
+        panel_shape(g.n_ext, nc, bn, tn);
+        g.nt_m = psvae_cdiv(M, 128), g.nt_n = nc, g.bn = bn;
+        const long long blocks = (long long)psvae_cdiv((long long)g.nt_m * split_k, 8) * 8 * g.nt_n;
+        PSVAE_REQUIRE(blocks < (1ll << 31), PSVAE_ETOOLARGE, "psvae_gemm_f32: grid too large");
+        dim3 grid((unsigned)blocks);
+        switch (tn) {
+            case 1: launch_panel<1, 32>(g, a_kc, b_kc, grid, s); break;
+            case 2: launch_panel<2, 32>(g, a_kc, b_kc, grid, s); break;
+            case 3: launch_panel<3, 32>(g, a_kc, b_kc, grid, s); break;
+            case 4: launch_panel<4, 32>(g, a_kc, b_kc, grid, s); break;
+            case 5: launch_panel<5, 32>(g, a_kc, b_kc, grid, s); break;
+            case 6: launch_panel<6, 32>(g, a_kc, b_kc, grid, s); break;
+            case 7: launch_panel<7, 16>(g, a_kc, b_kc, grid, s); break;
+            case 10: launch_panel<10, 16>(g, a_kc, b_kc, grid, s); break;
+            default: launch_panel<11, 16>(g, a_kc, b_kc, grid, s); break;
+        }
+    } else {
+        g.nt_m = psvae_cdiv(M, GB), g.nt_n = psvae_cdiv(g.n_ext, GB), g.bn = GB;
+        const long long blocks = (long long)psvae_cdiv((long long)g.nt_m * split_k, 8) * 8 * g.nt_n;
+        PSVAE_REQUIRE(blocks < (1ll << 31), PSVAE_ETOOLARGE, "psvae_gemm_f32: grid too large");
+        dim3 grid((unsigned)blocks);
+        if (a_kc && b_kc)
+            hipLaunchKernelGGL((gemm_generic_kernel<true, true>), grid, dim3(THREADS), 0, s, g);
+        else if (a_kc)
+            hipLaunchKernelGGL((gemm_generic_kernel<true, false>), grid, dim3(THREADS), 0, s, g);
+        else if (b_kc)
+            hipLaunchKernelGGL((gemm_generic_kernel<false, true>), grid, dim3(THREADS), 0, s, g);
+        else
+            hipLaunchKernelGGL((gemm_generic_kernel<false, false>), grid, dim3(THREADS), 0, s, g);
+    }
     PSVAE_CHECK_LAUNCH("psvae_gemm_f32");
     if (split_k > 1) {
-        const long long total = (long long)M * N;
+        const long long total = (long long)M * g.ws_ld;
         const int rb = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
         hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(rb), dim3(256), 0, s, g);
         PSVAE_CHECK_LAUNCH("psvae_gemm_f32 (split-K reduce)");

@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libpsvae_hip.so')
+LIB_PATH = os.environ.get('PSVAE_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libpsvae_hip.so')
 
 _c_int, _c_i64, _c_size = ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
 _c_f32, _c_f64, _c_ll, _p = ctypes.c_float, ctypes.c_double, ctypes.c_longlong, ctypes.c_void_p
@@ -33,7 +33,7 @@ _SIGNATURES = {
                                           _c_int, _p, _p, _c_size, _p]),
     'psvae_gemm_f32_workspace_bytes': (_c_size, [_c_int, _c_int, _c_int, _c_int]),
     'psvae_gemm_f32': (_c_int, [_c_int, _c_int, _c_int, _p, _p, _c_i64, _c_i64, _p, _c_i64, _c_i64, _p, _c_i64,
-                                _p, _c_int, _c_int, _c_int, _p, _c_size, _p]),
+                                _p, _p, _c_int, _c_int, _c_int, _p, _c_size, _p]),
     'psvae_colsum_workspace_bytes': (_c_size, [_c_int, _c_int]),
     'psvae_colsum_f32': (_c_int, [_c_int, _c_int, _p, _p, _c_i64, _p, _c_int, _p, _c_size, _p]),
     'psvae_segment_sum_fwd': (_c_int, [_c_int, _c_int, _p, _c_int, _p, _p, _p, _c_int, _p]),
@@ -185,15 +185,15 @@ def roofline_report(prof, hbm_peak_gbs, mfma_peak_tflops):
 
 # --------------------------------------------------------------------------- raw calls
 def gemm(M, N, K, A, sa_m, sa_k, B, sb_k, sb_n, C, ldc, bias=None, relu=False, accumulate=False,
-         amask=None, split_k=0):
+         amask=None, split_k=0, rowsum=None):
     L = lib()
     nbytes = L.psvae_gemm_f32_workspace_bytes(M, N, K, split_k)
     ws = workspace(nbytes, C.device) if nbytes else None
     with _Prof('gemm_f32_kernel', 2.0 * M * N * K):
         rc = L.psvae_gemm_f32(M, N, K, ptr(A, torch.float32), ptr(amask, torch.float32), sa_m, sa_k,
                               ptr(B, torch.float32), sb_k, sb_n, ptr(C, torch.float32), ldc,
-                              ptr(bias, torch.float32), 1 if relu else 0, 1 if accumulate else 0, split_k,
-                              ptr(ws), nbytes, _stream())
+                              ptr(bias, torch.float32), ptr(rowsum, torch.float32), 1 if relu else 0,
+                              1 if accumulate else 0, split_k, ptr(ws), nbytes, _stream())
     _check(rc, 'psvae_gemm_f32')
 
 

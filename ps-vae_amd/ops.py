@@ -134,11 +134,15 @@ class _Linear(Function):
             gx = torch.empty(M, K, dtype=torch.float32, device=g2.device)
             hip.gemm(M, K, N, g2, N, 1, w, w.stride(0), 1, gx, K, amask=mask)
             gx = gx.view(*ctx.lead, K)
-        if ctx.needs_input_grad[1]:
-            gw = torch.empty(N, K, dtype=torch.float32, device=g2.device)
-            hip.gemm(N, K, M, g2, 1, N, x2, _ld(x2), 1, gw, K, amask=mask, split_k=0)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        want_gb = ctx.has_bias and ctx.needs_input_grad[2]
+        if want_gb:
             gb = torch.empty(N, dtype=torch.float32, device=g2.device)
+        if ctx.needs_input_grad[1]:
+            # dW = dY^T X and, from the same pass over dY, db = dY^T 1
+            gw = torch.empty(N, K, dtype=torch.float32, device=g2.device)
+            hip.gemm(N, K, M, g2, 1, N, x2, _ld(x2), 1, gw, K, amask=mask, split_k=0,
+                     rowsum=gb if want_gb else None)
+        elif want_gb:
             hip.colsum(g2, gb, mask=mask)
         return gx, gw, gb, None
 
@@ -304,15 +308,18 @@ class _LinkCe(Function):
         if ctx.needs_input_grad[0]:
             g_hid = torch.empty(P, F, dtype=torch.float32, device=w.device)
             hip.link_ce_bwd_input(dlogits, w, g_loss, g_hid)
+        want_gb = ctx.has_bias and ctx.needs_input_grad[2]
+        if want_gb:
+            gb = torch.zeros(C, dtype=torch.float32, device=w.device)
         if ctx.needs_input_grad[1]:
             gw = torch.zeros(C, F, dtype=torch.float32, device=w.device)
             if P:
-                hip.gemm(C, F, P, dlogits, 1, C, hid2, _ld(hid2), 1, gw, F, split_k=0)
+                hip.gemm(C, F, P, dlogits, 1, C, hid2, _ld(hid2), 1, gw, F, split_k=0,
+                         rowsum=gb if want_gb else None)
             gw = gw * g_loss
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = torch.zeros(C, dtype=torch.float32, device=w.device)
-            if P:
-                hip.colsum(dlogits, gb)
+        elif want_gb and P:
+            hip.colsum(dlogits, gb)
+        if want_gb:
             gb = gb * g_loss
         return g_hid, gw, gb, None
 

@@ -35,7 +35,9 @@ def close(got, want, rel=REL, what=''):
 
 # ------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize('M,N,K', [(1, 1, 1), (7, 5, 3), (64, 64, 32), (130, 300, 200), (1000, 300, 300),
-                                   (333, 656, 328), (257, 4, 656), (40, 56, 400), (129, 65, 33)])
+                                   (333, 656, 328), (257, 4, 656), (40, 56, 400), (129, 65, 33),
+                                   (4096, 400, 1200), (2052, 328, 656), (1028, 96, 100), (512, 224, 64),
+                                   (900, 352, 44), (384, 708, 16)])
 def test_gemm_forward_shapes(M, N, K):
     from ps_vae_amd import hip
     d = dev()
@@ -56,8 +58,11 @@ def test_gemm_forward_shapes(M, N, K):
     # weight-gradient form dY^T X, split-K chosen by the library and forced
     for split in (0, 1, 5):
         gw = torch.full((N, K), 3.0, device=d)
-        hip.gemm(N, K, M, gy.to(d), 1, N, xd, K, 1, gw, K, amask=act.to(d), split_k=split, accumulate=True)
+        gb = torch.full((N,), -2.0, device=d)
+        hip.gemm(N, K, M, gy.to(d), 1, N, xd, K, 1, gw, K, amask=act.to(d), split_k=split, accumulate=True,
+                 rowsum=gb)
         close(gw, 3.0 + (gy.double() * (act > 0)).t() @ x.double(), what=f'dW split {split}')
+        close(gb, -2.0 + (gy.double() * (act > 0)).sum(0), what=f'db split {split}')
 
 
 def test_gemm_strided_output_and_operands():
