@@ -127,8 +127,10 @@ int psvae_embed_atom_bwd(int V, const int32_t *x, const int32_t *xp, const int32
  * Backward, given g = dL/d out and the CSR over SOURCE nodes (t_col = destination):
  *     g_x[j]     = g[j] + sum over edges e out of j of g[t_col[e]] * [x[j] + table[t_cls[e]] > 0]
  *     g_table[c] = sum over edges e with class c of the same masked rows
- * g_table is reduced deterministically through `workspace`
- * (psvae_gine_aggregate_bwd_workspace_bytes).
+ * `add` (optional, [V,H]) is added to g_x — the gradient that reaches x directly (the
+ * encoder's concatenated output slot).  accumulate_table != 0 adds to g_table (the SAME
+ * conv is applied t times, src/modules/encoder.py:57-59).  g_table is reduced
+ * deterministically through `workspace` (psvae_gine_aggregate_bwd_workspace_bytes).
  * ---------------------------------------------------------------------------------- */
 int psvae_gine_aggregate_fwd(int V, int H, int C, const float *x, int ldx, const float *table,
                              const int32_t *row_ptr, const int32_t *col, const uint8_t *cls,
@@ -137,8 +139,8 @@ size_t psvae_gine_aggregate_bwd_workspace_bytes(int V, int H, int C);
 int psvae_gine_aggregate_bwd(int V, int H, int C, const float *x, int ldx, const float *table,
                              const float *g, int ldg,
                              const int32_t *t_row_ptr, const int32_t *t_col, const uint8_t *t_cls,
-                             float *g_x, int ldgx, float *g_table,
-                             void *workspace, size_t workspace_bytes, void *stream);
+                             const float *add, int ldadd, float *g_x, int ldgx, float *g_table,
+                             int accumulate_table, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * f32 matrix product on the matrix cores (v_mfma_f32_32x32x2_f32: exact f32 FMA chains):

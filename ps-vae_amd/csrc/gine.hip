@@ -55,7 +55,8 @@ __global__ void gine_aggregate_bwd_kernel(int V, int C, int cols, int slots, int
                                           const float4 *__restrict__ g, int ldg4,
                                           const int32_t *__restrict__ t_row_ptr,
                                           const int32_t *__restrict__ t_col, const uint8_t *__restrict__ t_cls,
-                                          float4 *__restrict__ g_x, int ldgx4, float4 *__restrict__ partial) {
+                                          const float4 *__restrict__ add, int ldadd4, float4 *__restrict__ g_x,
+                                          int ldgx4, float4 *__restrict__ partial) {
     extern __shared__ float4 sh[];   // [slots][C][cols]
     const int c = threadIdx.x % cols, slot = threadIdx.x / cols;
     const bool active = slot < slots;
@@ -83,6 +84,7 @@ __global__ void gine_aggregate_bwd_kernel(int V, int C, int cols, int slots, int
                 for (int kk = 0; kk < MAXC; ++kk)
                     if (kk == k) gt[kk] = add4(gt[kk], m);
             }
+            if (add != nullptr) acc = add4(acc, add[(long long)j * ldadd4 + c]);
             g_x[(long long)j * ldgx4 + c] = acc;
         }
 #pragma unroll
@@ -99,19 +101,25 @@ __global__ void gine_aggregate_bwd_kernel(int V, int C, int cols, int slots, int
     }
 }
 
-// g_table[i] = sum over blocks b (ascending) of partial[b][i]; 4 threads share an output and
-// take blocks b = q, q+4, ...; their sums are added in q order.
+// g_table[i] (+)= sum over blocks b of partial[b][i] in a fixed order: a workgroup owns 32
+// consecutive outputs; 8 thread groups take blocks b = q, q+8, ...; their sums are added in
+// q order.
 __global__ void gine_table_reduce_kernel(int n_out, int n_blocks, const float *__restrict__ partial,
-                                         float *__restrict__ g_table) {
-    __shared__ float sh[4][64];
-    const int q = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int i = blockIdx.x * 64 + l;
+                                         float *__restrict__ g_table, int accumulate) {
+    __shared__ float sh[8][32];
+    const int q = threadIdx.x >> 5, l = threadIdx.x & 31;
+    const int i = blockIdx.x * 32 + l;
     float s = 0.f;
     if (i < n_out)
-        for (int b = q; b < n_blocks; b += 4) s += partial[(long long)b * n_out + i];
+        for (int b = q; b < n_blocks; b += 8) s += partial[(long long)b * n_out + i];
     sh[q][l] = s;
     __syncthreads();
-    if (q == 0 && i < n_out) g_table[i] = ((sh[0][l] + sh[1][l]) + sh[2][l]) + sh[3][l];
+    if (q == 0 && i < n_out) {
+        float t = sh[0][l];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += sh[k][l];
+        g_table[i] = accumulate ? g_table[i] + t : t;
+    }
 }
 
 struct Shape {
@@ -170,14 +178,17 @@ extern "C" size_t psvae_gine_aggregate_bwd_workspace_bytes(int V, int H, int C) 
 
 extern "C" int psvae_gine_aggregate_bwd(int V, int H, int C, const float *x, int ldx, const float *table,
                                         const float *g, int ldg, const int32_t *t_row_ptr,
-                                        const int32_t *t_col, const uint8_t *t_cls, float *g_x, int ldgx,
-                                        float *g_table, void *workspace, size_t workspace_bytes, void *stream) {
+                                        const int32_t *t_col, const uint8_t *t_cls, const float *add, int ldadd,
+                                        float *g_x, int ldgx, float *g_table, int accumulate_table,
+                                        void *workspace, size_t workspace_bytes, void *stream) {
     int rc = check_common("psvae_gine_aggregate_bwd", V, H, C, x, ldx);
     if (rc) return rc;
     PSVAE_REQUIRE(C <= 8, PSVAE_ETOOLARGE, "psvae_gine_aggregate_bwd: at most 8 edge classes (C=%d)", C);
     PSVAE_REQUIRE(g_table != nullptr, PSVAE_EINVAL, "psvae_gine_aggregate_bwd: g_table is null");
     hipStream_t s_ = (hipStream_t)stream;
-    if (V == 0) return (int)hipMemsetAsync(g_table, 0, (size_t)C * H * sizeof(float), s_);
+    if (V == 0) return accumulate_table ? PSVAE_OK : (int)hipMemsetAsync(g_table, 0, (size_t)C * H * sizeof(float), s_);
+    PSVAE_REQUIRE(add == nullptr || (psvae_aligned16(add) && ldadd % 4 == 0 && ldadd >= H), PSVAE_EINVAL,
+                  "psvae_gine_aggregate_bwd: bad `add` operand");
     PSVAE_REQUIRE(table && t_row_ptr && g && g_x && psvae_aligned16(table) && psvae_aligned16(g) &&
                       psvae_aligned16(g_x), PSVAE_EINVAL, "psvae_gine_aggregate_bwd: null or misaligned operand");
     PSVAE_REQUIRE(ldg % 4 == 0 && ldg >= H && ldgx % 4 == 0 && ldgx >= H, PSVAE_EINVAL,
@@ -191,17 +202,19 @@ extern "C" int psvae_gine_aggregate_bwd(int V, int H, int C, const float *x, int
     if (C <= 4)
         hipLaunchKernelGGL(gine_aggregate_bwd_kernel<4>, dim3(s.blocks), dim3(s.threads), lds, s_, V, C, s.cols,
                            s.slots, s.nodes_per_block, (const float4 *)x, ldx / 4, (const float4 *)table,
-                           (const float4 *)g, ldg / 4, t_row_ptr, t_col, t_cls, (float4 *)g_x, ldgx / 4,
+                           (const float4 *)g, ldg / 4, t_row_ptr, t_col, t_cls, (const float4 *)add, ldadd / 4, (float4 *)g_x,
+                           ldgx / 4,
                            (float4 *)workspace);
     else
         hipLaunchKernelGGL(gine_aggregate_bwd_kernel<8>, dim3(s.blocks), dim3(s.threads), lds, s_, V, C, s.cols,
                            s.slots, s.nodes_per_block, (const float4 *)x, ldx / 4, (const float4 *)table,
-                           (const float4 *)g, ldg / 4, t_row_ptr, t_col, t_cls, (float4 *)g_x, ldgx / 4,
+                           (const float4 *)g, ldg / 4, t_row_ptr, t_col, t_cls, (const float4 *)add, ldadd / 4, (float4 *)g_x,
+                           ldgx / 4,
                            (float4 *)workspace);
     PSVAE_CHECK_LAUNCH("psvae_gine_aggregate_bwd");
     const int n_out = C * H;
-    hipLaunchKernelGGL(gine_table_reduce_kernel, dim3(psvae_cdiv(n_out, 64)), dim3(256), 0, s_, n_out, s.blocks,
-                       (const float *)workspace, g_table);
+    hipLaunchKernelGGL(gine_table_reduce_kernel, dim3(psvae_cdiv(n_out, 32)), dim3(256), 0, s_, n_out, s.blocks,
+                       (const float *)workspace, g_table, accumulate_table);
     PSVAE_CHECK_LAUNCH("psvae_gine_aggregate_bwd (table reduce)");
     return PSVAE_OK;
 }

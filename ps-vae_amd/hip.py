@@ -30,7 +30,7 @@ _SIGNATURES = {
     'psvae_gine_aggregate_fwd': (_c_int, [_c_int, _c_int, _c_int, _p, _c_int, _p, _p, _p, _p, _p, _c_int, _p]),
     'psvae_gine_aggregate_bwd_workspace_bytes': (_c_size, [_c_int, _c_int, _c_int]),
     'psvae_gine_aggregate_bwd': (_c_int, [_c_int, _c_int, _c_int, _p, _c_int, _p, _p, _c_int, _p, _p, _p, _p,
-                                          _c_int, _p, _p, _c_size, _p]),
+                                          _c_int, _p, _c_int, _p, _c_int, _p, _c_size, _p]),
     'psvae_gemm_f32_workspace_bytes': (_c_size, [_c_int, _c_int, _c_int, _c_int]),
     'psvae_gemm_f32': (_c_int, [_c_int, _c_int, _c_int, _p, _p, _c_i64, _c_i64, _p, _c_i64, _c_i64, _p, _c_i64,
                                 _p, _p, _c_int, _c_int, _c_int, _p, _c_size, _p]),
@@ -220,19 +220,21 @@ def gine_aggregate_fwd(x, table, row_ptr, col, cls, out):
     _check(rc, 'psvae_gine_aggregate_fwd')
 
 
-def gine_aggregate_bwd(x, table, g, t_row_ptr, t_col, t_cls, g_x, g_table):
+def gine_aggregate_bwd(x, table, g, t_row_ptr, t_col, t_cls, g_x, g_table, add=None, accumulate_table=False):
     L = lib()
     V, H = x.shape
     C = table.shape[0]
     px, ldx = _rows(x)
     pg, ldg = _rows(g)
     pgx, ldgx = _rows(g_x)
+    padd, ldadd = _rows(add) if add is not None else (None, H)
     nbytes = L.psvae_gine_aggregate_bwd_workspace_bytes(V, H, C)
     ws = workspace(nbytes, x.device) if nbytes else None
     with _Prof('gine_aggregate_bwd_kernel', aggregate_bytes(V, t_col.numel(), H, backward=True)):
         rc = L.psvae_gine_aggregate_bwd(V, H, C, px, ldx, ptr(table, torch.float32), pg, ldg,
                                         ptr(t_row_ptr, torch.int32), ptr(t_col, torch.int32),
-                                        ptr(t_cls, torch.uint8), pgx, ldgx, ptr(g_table, torch.float32),
+                                        ptr(t_cls, torch.uint8), padd, ldadd, pgx, ldgx,
+                                        ptr(g_table, torch.float32), 1 if accumulate_table else 0,
                                         ptr(ws), nbytes, _stream())
     _check(rc, 'psvae_gine_aggregate_bwd')
 

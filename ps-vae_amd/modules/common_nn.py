@@ -6,14 +6,8 @@ import torch.nn as nn
 from .. import ops
 
 
-TRACE = None   # tests set this to a list to record (layer, fused_relu, output) of every Linear
-
-
 def run_linear(layer, x, relu=False):
-    out = ops.linear(x, layer.weight, layer.bias, relu=relu)
-    if TRACE is not None:
-        TRACE.append((layer, relu, out.detach()))
-    return out
+    return ops.linear(x, layer.weight, layer.bias, relu=relu)
 
 
 def run_sequential(seq, x):

@@ -6,6 +6,10 @@ from torch.autograd import Function
 
 from . import hip
 
+# Tests set this to a list: every fused Linear+ReLU output is appended in execution order
+# (used to count ReLU outputs whose sign differs from a float64 evaluation).
+RELU_TRACE = None
+
 
 # ------------------------------------------------------------------------ index containers
 class Csr:
@@ -114,6 +118,8 @@ class _Linear(Function):
         w = weight if weight.stride(1) == 1 else weight.contiguous()
         out = torch.empty(M, N, dtype=torch.float32, device=x2.device)
         hip.gemm(M, N, K, x2, _ld(x2), 1, w, 1, w.stride(0), out, N, bias=bias, relu=relu)
+        if relu and RELU_TRACE is not None:
+            RELU_TRACE.append(out.detach())
         ctx.relu = relu
         ctx.has_bias = bias is not None
         ctx.lead = x.shape[:-1]
@@ -178,6 +184,90 @@ class _GineAggregate(Function):
 def gine_aggregate(x, table, csr):
     """x + sum over incoming edges of ReLU(x[source] + table[bond class])."""
     return _GineAggregate.apply(x, table, csr)
+
+
+# ------------------------------------------------------------------------ fused GINE encoder
+class _GineEncoder(Function):
+    """Encoder.embed_node (src/modules/encoder.py:53-61) as ONE autograd node: node_trans,
+    then t rounds of [aggregate -> Linear+ReLU -> Linear] with the SAME conv weights, every
+    iterate written straight into its slot of the concatenated [V, t*H] output (no cat).
+
+    Backward runs the layers in reverse with hand-placed kernels: the ReLU derivative is
+    applied while the gradient operand is loaded, the slot gradient of an iterate is added
+    inside the aggregation backward, and the gradients of the shared conv weights are ONE
+    product each over the t iterations stacked along K (K = t*V) with the bias gradient
+    taken from the same pass."""
+
+    @staticmethod
+    def forward(ctx, x_in, w0, b0, table, w1, b1, w2, b2, csr, t):
+        x_in = _rows2d(x_in)
+        V, Din = x_in.shape
+        H = w0.shape[0]
+        dev = x_in.device
+        w0, w1, w2, table = w0.contiguous(), w1.contiguous(), w2.contiguous(), table.contiguous()
+        x0 = torch.empty(V, H, dtype=torch.float32, device=dev)
+        all_x = torch.empty(V, t * H, dtype=torch.float32, device=dev)
+        a = torch.empty(t, V, H, dtype=torch.float32, device=dev)
+        h = torch.empty(t, V, H, dtype=torch.float32, device=dev)
+        hip.gemm(V, H, Din, x_in, _ld(x_in), 1, w0, 1, Din, x0, H, bias=b0)
+        prev = x0
+        for i in range(t):
+            hip.gine_aggregate_fwd(prev, table, csr.row_ptr, csr.col, csr.cls, a[i])
+            hip.gemm(V, H, H, a[i], H, 1, w1, 1, H, h[i], H, bias=b1, relu=True)
+            if RELU_TRACE is not None:
+                RELU_TRACE.append(h[i].detach())
+            slot = all_x[:, i * H:(i + 1) * H]
+            hip.gemm(V, H, H, h[i], H, 1, w2, 1, H, slot, t * H, bias=b2)
+            prev = slot
+        ctx.csr, ctx.t = csr, t
+        ctx.save_for_backward(x_in, w0, table, w1, w2, x0, all_x, a, h)
+        return all_x
+
+    @staticmethod
+    def backward(ctx, g_all):
+        x_in, w0, table, w1, w2, x0, all_x, a, h = ctx.saved_tensors
+        csr, t = ctx.csr, ctx.t
+        V, Din = x_in.shape
+        H = w0.shape[0]
+        dev = x_in.device
+        g_all = g_all if (g_all.dtype == torch.float32 and g_all.is_contiguous()) else g_all.float().contiguous()
+        f32 = dict(dtype=torch.float32, device=dev)
+        gx = torch.empty(t, V, H, **f32)      # dL/d x_i (output of layer i), stacked for the dW2 product
+        gh = torch.empty(t, V, H, **f32)      # dL/d h_i before the ReLU gate
+        ga = torch.empty(V, H, **f32)
+        g_x0 = torch.empty(V, H, **f32)
+        g_table = torch.empty_like(table)
+        gx[t - 1].copy_(g_all[:, (t - 1) * H:])
+        for i in range(t - 1, -1, -1):
+            hip.gemm(V, H, H, gx[i], H, 1, w2, H, 1, gh[i], H)                  # through the last Linear
+            hip.gemm(V, H, H, gh[i], H, 1, w1, H, 1, ga, H, amask=h[i])         # through ReLU + first Linear
+            first = i == t - 1
+            if i > 0:
+                hip.gine_aggregate_bwd(all_x[:, (i - 1) * H:i * H], table, ga, csr.t_row_ptr, csr.t_col, csr.t_cls,
+                                       gx[i - 1], g_table, add=g_all[:, (i - 1) * H:i * H],
+                                       accumulate_table=not first)
+            else:
+                hip.gine_aggregate_bwd(x0, table, ga, csr.t_row_ptr, csr.t_col, csr.t_cls, g_x0, g_table,
+                                       accumulate_table=not first)
+        need = ctx.needs_input_grad
+        gw2, gb2 = torch.empty_like(w2), torch.empty(H, **f32)
+        gw1, gb1 = torch.empty_like(w1), torch.empty(H, **f32)
+        TV = t * V
+        gx2, gh2, h2, a2 = gx.view(TV, H), gh.view(TV, H), h.view(TV, H), a.view(TV, H)
+        hip.gemm(H, H, TV, gx2, 1, H, h2, H, 1, gw2, H, split_k=0, rowsum=gb2)
+        hip.gemm(H, H, TV, gh2, 1, H, a2, H, 1, gw1, H, amask=h2, split_k=0, rowsum=gb1)
+        gw0, gb0 = torch.empty_like(w0), torch.empty(H, **f32)
+        hip.gemm(H, Din, V, g_x0, 1, H, x_in, _ld(x_in), 1, gw0, Din, split_k=0, rowsum=gb0)
+        g_in = None
+        if need[0]:
+            g_in = torch.empty(V, Din, **f32)
+            hip.gemm(V, Din, H, g_x0, H, 1, w0, Din, 1, g_in, Din)
+        return g_in, gw0, gb0, g_table, gw1, gb1, gw2, gb2, None, None
+
+
+def gine_encoder(x_in, w0, b0, table, w1, b1, w2, b2, csr, t):
+    """[V, t*H] concatenation of the t GINE iterates of node_trans(x_in)."""
+    return _GineEncoder.apply(x_in, w0, b0, table, w1, b1, w2, b2, csr, t)
 
 
 # ------------------------------------------------------------------------ embed_atom

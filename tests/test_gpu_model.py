@@ -135,7 +135,7 @@ def test_default_width_batch_256_against_oracle(tokenizer):
     the float64 oracle's; they must be at most 8, and only when there is such a flip is the
     bound on the gradients relaxed to 2e-3 of the tensor's largest entry."""
     import copy
-    import ps_vae_amd.modules.common_nn as common_nn
+    from ps_vae_amd import ops as hip_ops
     from ps_vae_amd.data.collate import collate_packed
     from ps_vae_amd.data.packed import PackedMolecules
     from ps_vae_amd.data.synthetic import synthetic_step1
@@ -169,12 +169,12 @@ def test_default_width_batch_256_against_oracle(tokenizer):
     batch = collate_packed(packed.to_device(dev()), np.arange(B), uniforms=torch.from_numpy(uniforms).to(dev()),
                            atom_pad=tokenizer.atom_pad_idx(), piece_pad=tokenizer.pad_idx(), reference_layout=False)
     assert batch.num_uniforms == used
-    common_nn.TRACE = []
+    hip_ops.RELU_TRACE = []
     try:
         gpl, (grec, gpiece, gedge, gkl) = model(batch, eps=eps.to(dev()))
-        relu_gpu = [out for _, relu, out in common_nn.TRACE if relu]
+        relu_gpu = list(hip_ops.RELU_TRACE)
     finally:
-        common_nn.TRACE = None
+        hip_ops.RELU_TRACE = None
     loss = model.weighted_loss(gpl, grec, gkl)
     loss.backward()
     for name, a, b in [('total', loss, ref_loss), ('pred', gpl, pl), ('piece', gpiece, piece), ('edge', gedge, edge),
