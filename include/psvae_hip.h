@@ -193,6 +193,21 @@ int psvae_rsample_kl_bwd(int B, int L, const float *mean, const float *lv_pre, c
                          void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * One time step of the piece language model's GRU (nn.GRU at
+ * src/modules/vae_piece_decoder.py:29,89; PyTorch gate order r, z, n), element-wise part:
+ * gi = x_t W_ih^T + b_ih and gh = h_prev W_hh^T + b_hh ([B,3H], computed by psvae_gemm_f32),
+ *     r = s(gi_r + gh_r), z = s(gi_z + gh_z), n = tanh(gi_n + r * gh_n),
+ *     h = (1 - z) * n + z * h_prev;   gates [B,3H] keeps (r, z, n) for the backward.
+ * Backward: given dh (+ optional dh_extra) = dL/dh, writes dgi, dgh [B,3H] (gradients of the
+ * two pre-activation inputs) and dh_prev = dh * z (the direct path; the caller adds dgh W_hh).
+ * ---------------------------------------------------------------------------------- */
+int psvae_gru_cell_fwd(int B, int H, const float *gi, const float *gh, const float *h_prev,
+                       float *h, float *gates, void *stream);
+int psvae_gru_cell_bwd(int B, int H, const float *gates, const float *gh, const float *h_prev,
+                       const float *dh, const float *dh_extra, float *dgi, float *dgh,
+                       float *dh_prev, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * Link predictor input (src/modules/vae_piece_decoder.py:99-109) without the [B,N,N,*]
  * intermediates: feats[p] = [ h[src[p]] | h[dst[p]] | z[graph[p]] ], width 2H + L.
  * Backward sums the rows back per node / per graph without atomics: graph b owns pairs

@@ -131,6 +131,44 @@ __global__ void rsample_kl_bwd_kernel(int B, int L, const float *__restrict__ me
     }
 }
 
+// ---------------------------------------------------------------- GRU cell (piece LM)
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// PyTorch gate order (r, z, n): r = s(gi_r + gh_r), z = s(gi_z + gh_z),
+// n = tanh(gi_n + r * gh_n), h = (1 - z) * n + z * h_prev.
+__global__ void gru_cell_fwd_kernel(int B, int H, const float *__restrict__ gi, const float *__restrict__ gh,
+                                    const float *__restrict__ hp, float *__restrict__ h, float *__restrict__ gates) {
+    const int total = B * H;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int b = i / H, j = i - b * H;
+        const long long o = (long long)b * 3 * H + j;
+        const float r = sigmoidf_(gi[o] + gh[o]);
+        const float z = sigmoidf_(gi[o + H] + gh[o + H]);
+        const float n = tanhf(gi[o + 2 * H] + r * gh[o + 2 * H]);
+        gates[o] = r, gates[o + H] = z, gates[o + 2 * H] = n;
+        h[i] = (1.0f - z) * n + z * hp[i];
+    }
+}
+
+__global__ void gru_cell_bwd_kernel(int B, int H, const float *__restrict__ gates, const float *__restrict__ gh,
+                                    const float *__restrict__ hp, const float *__restrict__ dh,
+                                    const float *__restrict__ dh_extra, float *__restrict__ dgi,
+                                    float *__restrict__ dgh, float *__restrict__ dhp) {
+    const int total = B * H;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int b = i / H, j = i - b * H;
+        const long long o = (long long)b * 3 * H + j;
+        const float r = gates[o], z = gates[o + H], n = gates[o + 2 * H];
+        const float d = dh[i] + (dh_extra ? dh_extra[i] : 0.f);
+        const float dn_pre = d * (1.0f - z) * (1.0f - n * n);
+        const float dz_pre = d * (hp[i] - n) * z * (1.0f - z);
+        const float dr_pre = dn_pre * gh[o + 2 * H] * r * (1.0f - r);
+        dgi[o] = dr_pre, dgi[o + H] = dz_pre, dgi[o + 2 * H] = dn_pre;
+        dgh[o] = dr_pre, dgh[o + H] = dz_pre, dgh[o + 2 * H] = dn_pre * r;
+        dhp[i] = d * z;
+    }
+}
+
 // ---------------------------------------------------------------- pair features
 __global__ void pair_gather_fwd_kernel(int P, int h4, int l4, const float4 *__restrict__ h, int ldh4,
                                        const float4 *__restrict__ z, int ldz4, const int32_t *__restrict__ src,
@@ -418,6 +456,29 @@ extern "C" int psvae_rsample_kl_bwd(int B, int L, const float *mean, const float
     hipLaunchKernelGGL(rsample_kl_bwd_kernel, dim3(grid_for((long long)B * L, 256)), dim3(256), 0, (hipStream_t)stream,
                        B, L, mean, lv_pre, eps, g_z, g_kl, g_mean, g_lv_pre);
     PSVAE_CHECK_LAUNCH("psvae_rsample_kl_bwd");
+    return PSVAE_OK;
+}
+
+extern "C" int psvae_gru_cell_fwd(int B, int H, const float *gi, const float *gh, const float *h_prev, float *h,
+                                  float *gates, void *stream) {
+    PSVAE_REQUIRE(B >= 0 && H > 0 && (long long)B * H < (1ll << 31), PSVAE_EINVAL, "psvae_gru_cell_fwd: bad sizes");
+    if (B == 0) return PSVAE_OK;
+    PSVAE_REQUIRE(gi && gh && h_prev && h && gates, PSVAE_EINVAL, "psvae_gru_cell_fwd: null pointer");
+    hipLaunchKernelGGL(gru_cell_fwd_kernel, dim3(grid_for((long long)B * H, 256)), dim3(256), 0, (hipStream_t)stream, B,
+                       H, gi, gh, h_prev, h, gates);
+    PSVAE_CHECK_LAUNCH("psvae_gru_cell_fwd");
+    return PSVAE_OK;
+}
+
+extern "C" int psvae_gru_cell_bwd(int B, int H, const float *gates, const float *gh, const float *h_prev,
+                                  const float *dh, const float *dh_extra, float *dgi, float *dgh, float *dh_prev,
+                                  void *stream) {
+    PSVAE_REQUIRE(B >= 0 && H > 0 && (long long)B * H < (1ll << 31), PSVAE_EINVAL, "psvae_gru_cell_bwd: bad sizes");
+    if (B == 0) return PSVAE_OK;
+    PSVAE_REQUIRE(gates && gh && h_prev && dh && dgi && dgh && dh_prev, PSVAE_EINVAL, "psvae_gru_cell_bwd: null pointer");
+    hipLaunchKernelGGL(gru_cell_bwd_kernel, dim3(grid_for((long long)B * H, 256)), dim3(256), 0, (hipStream_t)stream, B,
+                       H, gates, gh, h_prev, dh, dh_extra, dgi, dgh, dh_prev);
+    PSVAE_CHECK_LAUNCH("psvae_gru_cell_bwd");
     return PSVAE_OK;
 }
 

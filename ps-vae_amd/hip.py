@@ -40,6 +40,8 @@ _SIGNATURES = {
     'psvae_segment_sum_bwd': (_c_int, [_c_int, _c_int, _p, _c_int, _p, _p, _p, _c_int, _p]),
     'psvae_rsample_kl_fwd': (_c_int, [_c_int, _c_int, _p, _p, _p, _p, _p, _p]),
     'psvae_rsample_kl_bwd': (_c_int, [_c_int, _c_int, _p, _p, _p, _p, _p, _p, _p, _p]),
+    'psvae_gru_cell_fwd': (_c_int, [_c_int, _c_int, _p, _p, _p, _p, _p, _p]),
+    'psvae_gru_cell_bwd': (_c_int, [_c_int, _c_int, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     'psvae_pair_gather_fwd': (_c_int, [_c_int, _c_int, _c_int, _p, _c_int, _p, _c_int, _p, _p, _p, _p, _p]),
     'psvae_pair_gather_bwd': (_c_int, [_c_int, _c_int, _c_int, _p, _p, _p, _p, _p, _p, _p, _c_int, _p, _c_int, _p]),
     'psvae_link_ce_workspace_bytes': (_c_size, [_c_int]),
@@ -281,6 +283,20 @@ def rsample_kl_bwd(mean, lv_pre, eps, g_z, g_kl, g_mean, g_lv_pre):
                                       ptr(eps, torch.float32), ptr(g_z, torch.float32), ptr(g_kl, torch.float32),
                                       ptr(g_mean, torch.float32), ptr(g_lv_pre, torch.float32), _stream()),
            'psvae_rsample_kl_bwd')
+
+
+def gru_cell_fwd(gi, gh, h_prev, h, gates):
+    B, H = h_prev.shape
+    f = torch.float32
+    _check(lib().psvae_gru_cell_fwd(B, H, ptr(gi, f), ptr(gh, f), ptr(h_prev, f), ptr(h, f), ptr(gates, f),
+                                    _stream()), 'psvae_gru_cell_fwd')
+
+
+def gru_cell_bwd(gates, gh, h_prev, dh, dh_extra, dgi, dgh, dh_prev):
+    B, H = h_prev.shape
+    f = torch.float32
+    _check(lib().psvae_gru_cell_bwd(B, H, ptr(gates, f), ptr(gh, f), ptr(h_prev, f), ptr(dh, f), ptr(dh_extra, f),
+                                    ptr(dgi, f), ptr(dgh, f), ptr(dh_prev, f), _stream()), 'psvae_gru_cell_bwd')
 
 
 def pair_gather_fwd(h, z, src, dst, graph, feats):

@@ -3,9 +3,10 @@
 :203-241).
 
 What runs where: embeddings, the second GINE pass, the pair gather, the link MLP, the link
-loss and the reparameterised latent are HIP kernels (ps_vae_amd.ops); the teacher-forced
-GRU piece language model (:81-90) is PyTorch's stock GRU on the GPU.  The RDKit-based
-molecule assembly of `inference` (:160-201, 243-274) is outside the hot path."""
+loss, the reparameterised latent and the teacher-forced GRU piece language model (:81-90)
+are HIP kernels (ps_vae_amd.ops); `self.rnn` stays an nn.GRU so that the parameter names
+match, but only its weights are used.  The RDKit-based molecule assembly of `inference`
+(:160-201, 243-274) is outside the hot path."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -56,9 +57,14 @@ class VAEPieceDecoder(nn.Module):
 
     def piece_logits(self, z_vecs, pieces):
         """:81-90 — teacher-forced GRU over the piece sequence, initial state from z."""
-        emb = self.piece_embedding(pieces)
-        init_hidden = run_linear(self.latent_to_rnn_hidden, z_vecs).unsqueeze(0)
-        output, _ = self.rnn(emb[:, :-1], init_hidden)
+        rnn = self.rnn
+        init_hidden = run_linear(self.latent_to_rnn_hidden, z_vecs)
+        if rnn.num_layers == 1 and not rnn.bidirectional and rnn.bias:
+            # time-major ids -> [T,B,E] embeddings -> HIP GRU; logits returned batch-major
+            emb = self.piece_embedding(pieces[:, :-1].t())
+            hs = ops.gru(emb, init_hidden, rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.bias_ih_l0, rnn.bias_hh_l0)
+            return run_linear(self.to_vocab, hs).transpose(0, 1)
+        output, _ = rnn(self.piece_embedding(pieces)[:, :-1], init_hidden.unsqueeze(0))
         return run_linear(self.to_vocab, output)
 
     def link_logits(self, node_embedding, z_vecs, pairs, golden=None):

@@ -343,6 +343,69 @@ def rsample_kl(mean, lv_pre, eps):
     return _RsampleKl.apply(mean, lv_pre, eps)
 
 
+# ------------------------------------------------------------------------ GRU (piece LM)
+class _Gru(Function):
+    """Single-layer GRU over a time-major sequence (the piece language model,
+    src/modules/vae_piece_decoder.py:29,85-89): the input projection of ALL steps is one
+    GEMM, each step is one GEMM for the hidden projection plus one fused gate kernel, and
+    the weight gradients are one GEMM each over the steps stacked along K."""
+
+    @staticmethod
+    def forward(ctx, x, h0, w_ih, w_hh, b_ih, b_hh):
+        T, B, E = x.shape
+        H = h0.shape[1]
+        dev = x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        x = x.contiguous()
+        w_ih, w_hh = w_ih.contiguous(), w_hh.contiguous()
+        gi = torch.empty(T, B, 3 * H, **f32)
+        gh = torch.empty(T, B, 3 * H, **f32)
+        gates = torch.empty(T, B, 3 * H, **f32)
+        hall = torch.empty(T + 1, B, H, **f32)
+        hall[0].copy_(h0)
+        if T * B:
+            hip.gemm(T * B, 3 * H, E, x.view(T * B, E), E, 1, w_ih, 1, E, gi.view(T * B, 3 * H), 3 * H, bias=b_ih)
+        for t in range(T):
+            hip.gemm(B, 3 * H, H, hall[t], H, 1, w_hh, 1, H, gh[t], 3 * H, bias=b_hh)
+            hip.gru_cell_fwd(gi[t], gh[t], hall[t], hall[t + 1], gates[t])
+        ctx.save_for_backward(x, w_ih, w_hh, gh, gates, hall)
+        ctx.has_bias = (b_ih is not None, b_hh is not None)
+        return hall[1:]
+
+    @staticmethod
+    def backward(ctx, g_out):
+        x, w_ih, w_hh, gh, gates, hall = ctx.saved_tensors
+        T, B, E = x.shape
+        H = hall.shape[2]
+        f32 = dict(dtype=torch.float32, device=x.device)
+        g_out = g_out if (g_out.dtype == torch.float32 and g_out.is_contiguous()) else g_out.float().contiguous()
+        dgi = torch.empty(T, B, 3 * H, **f32)
+        dgh = torch.empty(T, B, 3 * H, **f32)
+        dh = torch.zeros(B, H, **f32)          # gradient flowing into h_t from step t+1
+        nxt = torch.empty(B, H, **f32)
+        for t in range(T - 1, -1, -1):
+            hip.gru_cell_bwd(gates[t], gh[t], hall[t], g_out[t], dh, dgi[t], dgh[t], nxt)
+            hip.gemm(B, H, 3 * H, dgh[t], 3 * H, 1, w_hh, H, 1, nxt, H, accumulate=True)   # + dgh W_hh
+            dh, nxt = nxt, dh
+        g_wih, g_whh = torch.empty_like(w_ih), torch.empty_like(w_hh)
+        g_bih = torch.empty(3 * H, **f32) if ctx.has_bias[0] else None
+        g_bhh = torch.empty(3 * H, **f32) if ctx.has_bias[1] else None
+        TB = T * B
+        hip.gemm(3 * H, E, TB, dgi.view(TB, 3 * H), 1, 3 * H, x.view(TB, E), E, 1, g_wih, E, split_k=0, rowsum=g_bih)
+        hip.gemm(3 * H, H, TB, dgh.view(TB, 3 * H), 1, 3 * H, hall[:T].reshape(TB, H), H, 1, g_whh, H, split_k=0,
+                 rowsum=g_bhh)
+        g_x = None
+        if ctx.needs_input_grad[0]:
+            g_x = torch.empty(T, B, E, **f32)
+            hip.gemm(TB, E, 3 * H, dgi.view(TB, 3 * H), 3 * H, 1, w_ih, E, 1, g_x.view(TB, E), E)
+        return g_x, dh, g_wih, g_whh, g_bih, g_bhh
+
+
+def gru(x, h0, w_ih, w_hh, b_ih, b_hh):
+    """x [T,B,E] time-major, h0 [B,H] -> hidden states [T,B,H]."""
+    return _Gru.apply(x, h0, w_ih, w_hh, b_ih, b_hh)
+
+
 # ------------------------------------------------------------------------ pair features
 class _PairGather(Function):
     @staticmethod

@@ -239,6 +239,32 @@ def test_rsample_kl_fwd_bwd():
     close(pd.grad, pre.grad, what='d/dlogvar')
 
 
+@pytest.mark.parametrize('T,B', [(1, 3), (7, 300), (9, 33)])
+def test_gru_fwd_bwd(T, B):
+    from ps_vae_amd import ops
+    d = dev()
+    E, H = 100, 200
+    torch.manual_seed(T * 100 + B)
+    ref = torch.nn.GRU(E, H, batch_first=True).double()
+    x = torch.randn(B, T, E, dtype=torch.float64, requires_grad=True)
+    h0 = torch.randn(B, H, dtype=torch.float64, requires_grad=True)
+    out, _ = ref(x, h0.unsqueeze(0))
+    gy = torch.randn(B, T, H, dtype=torch.float64)
+    out.backward(gy)
+    params = [p.detach().float().to(d).requires_grad_() for p in
+              (ref.weight_ih_l0, ref.weight_hh_l0, ref.bias_ih_l0, ref.bias_hh_l0)]
+    xd = x.detach().float().transpose(0, 1).contiguous().to(d).requires_grad_()
+    hd = h0.detach().float().to(d).requires_grad_()
+    hs = ops.gru(xd, hd, *params)                     # [T,B,H]
+    hs.backward(gy.float().transpose(0, 1).contiguous().to(d))
+    close(hs.transpose(0, 1), out, what='GRU hidden states')
+    close(xd.grad.transpose(0, 1), x.grad, what='d GRU / dx')
+    close(hd.grad, h0.grad, what='d GRU / dh0')
+    for p, r, name in zip(params, (ref.weight_ih_l0, ref.weight_hh_l0, ref.bias_ih_l0, ref.bias_hh_l0),
+                          ('w_ih', 'w_hh', 'b_ih', 'b_hh')):
+        close(p.grad, r.grad, what=f'd GRU / d {name}')
+
+
 def make_pairs(B, N, seed, p=0.15):
     g = torch.Generator().manual_seed(seed)
     sel = torch.rand(B, N, N, generator=g) < p
