@@ -115,6 +115,12 @@ int psvae_embed_atom_bwd(int V, const int32_t *x, const int32_t *xp, const int32
                          const float *g_out, int n_atom, int d_atom, int n_piece, int d_piece,
                          int n_pos, int d_pos,
                          float *g_atom, float *g_piece, float *g_pos, void *stream);
+/* Indicator rows for the deterministic form of the same backward: out[v][j] = 1 where
+ * j == x[v], j == n_atom + xp[v] or j == n_atom + n_piece + xq[v], else 0, for j < ld
+ * (ld % 4 == 0, ld >= n_atom + n_piece + n_pos).  out^T g_out, one psvae_gemm_f32 call,
+ * then holds the three table gradients in its diagonal blocks. */
+int psvae_embed_atom_onehot(int V, const int32_t *x, const int32_t *xp, const int32_t *xq,
+                            int n_atom, int n_piece, int n_pos, float *out, int ld, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * GINE aggregation, the message/aggregate half of torch_geometric.nn.GINEConv as called at

@@ -66,6 +66,23 @@ __global__ void embed_atom_bwd_kernel(int V, const int32_t *__restrict__ x, cons
     }
 }
 
+__global__ void embed_atom_onehot_kernel(int V, const int32_t *__restrict__ x, const int32_t *__restrict__ xp,
+                                         const int32_t *__restrict__ xq, int na, int np, float4 *__restrict__ out,
+                                         int ld4) {
+    const long long total = (long long)V * ld4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int v = (int)(i / ld4), j = (int)(i - (long long)v * ld4) * 4;
+        const int a = x[v], b = na + xp[v], c = na + np + xq[v];
+        float4 o;
+        o.x = (j == a || j == b || j == c) ? 1.f : 0.f;
+        o.y = (j + 1 == a || j + 1 == b || j + 1 == c) ? 1.f : 0.f;
+        o.z = (j + 2 == a || j + 2 == b || j + 2 == c) ? 1.f : 0.f;
+        o.w = (j + 3 == a || j + 3 == b || j + 3 == c) ? 1.f : 0.f;
+        out[i] = o;
+    }
+}
+
 // ---------------------------------------------------------------- segment sum (embed_graph)
 __global__ void segment_sum_fwd_kernel(int cols, const float4 *__restrict__ x, int ldx4,
                                        const int32_t *__restrict__ seg_begin, const int32_t *__restrict__ seg_end,
@@ -237,16 +254,24 @@ __global__ void pair_gather_bwd_kernel(int h4, int l4, int slots, const float4 *
 }
 
 // ---------------------------------------------------------------- link loss
-template <int MAXC>
+// One wave per candidate pair: dot products of the pair's hidden row with the C rows of W
+// (staged in LDS when they fit), then softmax / loss / argmax on lane 0.  VEC: F and ldhid
+// are multiples of 4 and the rows are 16-byte aligned, so lanes read float4.
+template <int MAXC, bool VEC, bool LDSW>
 __global__ __launch_bounds__(256) void link_ce_fwd_kernel(int P, int F, int C, const float *__restrict__ hid,
                                                           int ldhid, const float *__restrict__ W,
                                                           const float *__restrict__ bias,
                                                           const int32_t *__restrict__ golden,
                                                           float *__restrict__ logits, float *__restrict__ dlogits,
                                                           float *__restrict__ part_loss, int *__restrict__ part_ok) {
+    extern __shared__ __align__(16) float sW[];
     __shared__ float sh_loss[4];
     __shared__ int sh_ok[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (LDSW) {
+        for (int i = threadIdx.x; i < C * F; i += 256) sW[i] = W[i];
+        __syncthreads();
+    }
     float loss_acc = 0.f;
     int ok_acc = 0;
     for (int p = blockIdx.x * 4 + wave; p < P; p += gridDim.x * 4) {
@@ -254,11 +279,26 @@ __global__ __launch_bounds__(256) void link_ce_fwd_kernel(int P, int F, int C, c
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) dot[c] = 0.f;
         const float *row = hid + (long long)p * ldhid;
-        for (int f = lane; f < F; f += 64) {
-            const float hv = row[f];
+        if (VEC) {
+            const float4 *row4 = reinterpret_cast<const float4 *>(row);
+            const int F4 = F >> 2;
+            for (int f = lane; f < F4; f += 64) {
+                const float4 hv = row4[f];
 #pragma unroll
-            for (int c = 0; c < MAXC; ++c)
-                if (c < C) dot[c] += hv * W[c * F + f];
+                for (int c = 0; c < MAXC; ++c)
+                    if (c < C) {
+                        const float4 wv = LDSW ? reinterpret_cast<const float4 *>(sW)[c * F4 + f]
+                                               : reinterpret_cast<const float4 *>(W)[c * F4 + f];
+                        dot[c] += (hv.x * wv.x + hv.y * wv.y) + (hv.z * wv.z + hv.w * wv.w);
+                    }
+            }
+        } else {
+            for (int f = lane; f < F; f += 64) {
+                const float hv = row[f];
+#pragma unroll
+                for (int c = 0; c < MAXC; ++c)
+                    if (c < C) dot[c] += hv * (LDSW ? sW[c * F + f] : W[c * F + f]);
+            }
         }
 #pragma unroll
         for (int c = 0; c < MAXC; ++c)
@@ -407,6 +447,22 @@ extern "C" int psvae_embed_atom_bwd(int V, const int32_t *x, const int32_t *xp, 
     return PSVAE_OK;
 }
 
+extern "C" int psvae_embed_atom_onehot(int V, const int32_t *x, const int32_t *xp, const int32_t *xq, int n_atom,
+                                       int n_piece, int n_pos, float *out, int ld, void *stream) {
+    PSVAE_REQUIRE(V >= 0 && n_atom >= 0 && n_piece >= 0 && n_pos >= 0, PSVAE_EINVAL,
+                  "psvae_embed_atom_onehot: bad sizes");
+    PSVAE_REQUIRE(ld % 4 == 0 && ld >= n_atom + n_piece + n_pos && ld > 0, PSVAE_EINVAL,
+                  "psvae_embed_atom_onehot: ld=%d must be a multiple of 4 covering %d ids", ld,
+                  n_atom + n_piece + n_pos);
+    if (V == 0) return PSVAE_OK;
+    PSVAE_REQUIRE(x && xp && xq && out && psvae_aligned16(out), PSVAE_EINVAL,
+                  "psvae_embed_atom_onehot: null or misaligned pointer");
+    hipLaunchKernelGGL(embed_atom_onehot_kernel, dim3(grid_for((long long)V * (ld / 4), 256, 16384)), dim3(256), 0,
+                       (hipStream_t)stream, V, x, xp, xq, n_atom, n_piece, (float4 *)out, ld / 4);
+    PSVAE_CHECK_LAUNCH("psvae_embed_atom_onehot");
+    return PSVAE_OK;
+}
+
 static int check_seg(const char *fn, int B, int W, const void *a, int lda, const void *b, int ldb, const void *s0,
                      const void *s1) {
     PSVAE_REQUIRE(B >= 0 && W > 0 && W % 4 == 0, PSVAE_EINVAL, "%s: W=%d must be a positive multiple of 4", fn, W);
@@ -539,12 +595,23 @@ extern "C" int psvae_link_ce_fwd(int P, int F, int C, const float *hid, int ldhi
     float *part_loss = (float *)workspace;
     int *part_ok = (int *)(part_loss + blocks);
     hipStream_t s = (hipStream_t)stream;
-    if (C <= 4)
-        hipLaunchKernelGGL(link_ce_fwd_kernel<4>, dim3(blocks), dim3(256), 0, s, P, F, C, hid, ldhid, W, b, golden,
-                           logits, dlogits, part_loss, part_ok);
-    else
-        hipLaunchKernelGGL(link_ce_fwd_kernel<8>, dim3(blocks), dim3(256), 0, s, P, F, C, hid, ldhid, W, b, golden,
-                           logits, dlogits, part_loss, part_ok);
+    const bool vec = (F % 4 == 0) && (ldhid % 4 == 0) && ((uintptr_t)hid % 16 == 0) && ((uintptr_t)W % 16 == 0);
+    const size_t w_bytes = (size_t)C * F * sizeof(float);
+    const bool ldsw = w_bytes <= 48 * 1024;
+    const size_t shm = ldsw ? w_bytes : 0;
+#define PSVAE_LINK_CE(MAXC, VEC, LDSW)                                                                            \
+    hipLaunchKernelGGL((link_ce_fwd_kernel<MAXC, VEC, LDSW>), dim3(blocks), dim3(256), shm, s, P, F, C, hid, ldhid, \
+                       W, b, golden, logits, dlogits, part_loss, part_ok)
+    if (C <= 4) {
+        if (vec && ldsw) PSVAE_LINK_CE(4, true, true);
+        else if (ldsw) PSVAE_LINK_CE(4, false, true);
+        else PSVAE_LINK_CE(4, false, false);
+    } else {
+        if (vec && ldsw) PSVAE_LINK_CE(8, true, true);
+        else if (ldsw) PSVAE_LINK_CE(8, false, true);
+        else PSVAE_LINK_CE(8, false, false);
+    }
+#undef PSVAE_LINK_CE
     PSVAE_CHECK_LAUNCH("psvae_link_ce_fwd");
     hipLaunchKernelGGL(link_ce_finish_kernel, dim3(1), dim3(64), 0, s, P, blocks, part_loss, part_ok, loss, n_correct);
     PSVAE_CHECK_LAUNCH("psvae_link_ce_fwd (finish)");

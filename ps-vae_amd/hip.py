@@ -27,6 +27,7 @@ _SIGNATURES = {
     'psvae_embed_atom_fwd': (_c_int, [_c_int, _p, _p, _p, _p, _c_int, _c_int, _p, _c_int, _c_int, _p, _c_int,
                                       _c_int, _p, _p]),
     'psvae_embed_atom_bwd': (_c_int, [_c_int, _p, _p, _p, _p] + [_c_int] * 6 + [_p, _p, _p, _p]),
+    'psvae_embed_atom_onehot': (_c_int, [_c_int, _p, _p, _p, _c_int, _c_int, _c_int, _p, _c_int, _p]),
     'psvae_gine_aggregate_fwd': (_c_int, [_c_int, _c_int, _c_int, _p, _c_int, _p, _p, _p, _p, _p, _c_int, _p]),
     'psvae_gine_aggregate_bwd_workspace_bytes': (_c_size, [_c_int, _c_int, _c_int]),
     'psvae_gine_aggregate_bwd': (_c_int, [_c_int, _c_int, _c_int, _p, _c_int, _p, _p, _c_int, _p, _p, _p, _p,
@@ -247,6 +248,12 @@ def embed_atom_fwd(x, xp, xq, ea, ep, eq, out):
                                       ptr(ep, torch.float32), ep.shape[0], ep.shape[1],
                                       ptr(eq, torch.float32), eq.shape[0], eq.shape[1],
                                       ptr(out, torch.float32), _stream()), 'psvae_embed_atom_fwd')
+
+
+def embed_atom_onehot(x, xp, xq, n_atom, n_piece, n_pos, out):
+    _check(lib().psvae_embed_atom_onehot(x.numel(), ptr(x, torch.int32), ptr(xp, torch.int32), ptr(xq, torch.int32),
+                                         n_atom, n_piece, n_pos, ptr(out, torch.float32), out.stride(0), _stream()),
+           'psvae_embed_atom_onehot')
 
 
 def embed_atom_bwd(x, xp, xq, g, ga, gp, gq):

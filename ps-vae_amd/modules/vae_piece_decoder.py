@@ -12,7 +12,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import hip, ops
-from .common_nn import MLP, run_linear
+from .common_nn import MLP, run_linear, run_sequential
 from .encoder import Encoder
 
 
@@ -71,11 +71,23 @@ class VAEPieceDecoder(nn.Module):
         """:99-110 (+ :115 when `golden` is given).  node_embedding [V,H] in the node ids the
         pair list uses.  Returns (logits, loss or None, n_correct or None)."""
         feats = ops.pair_gather(node_embedding, z_vecs, pairs)
-        hid = self.edge_predictor[0](feats)
-        last = self.edge_predictor[1]
+        mlp, last = self.edge_predictor[0], self.edge_predictor[1]
+        seq = mlp.seq
+        if isinstance(seq, nn.Sequential) and len(seq) > 1 and isinstance(seq[-1], nn.Linear):
+            # No activation sits between the MLP's output layer and the class layer, so the
+            # two are one affine map: W = W_last W_out, b = W_last b_out + b_last.  The wide
+            # intermediate [P, mlp_in] is never formed; autograd carries the gradient of
+            # (W, b) back to both layers through the two small products.
+            inner = seq[-1]
+            hid = run_sequential(seq[:-1], feats)
+            weight = ops.linear(last.weight, inner.weight.t())
+            bias = ops.linear(inner.bias.unsqueeze(0), last.weight, last.bias).squeeze(0)
+        else:
+            hid = mlp(feats)
+            weight, bias = last.weight, last.bias
         if golden is None:
-            return run_linear(last, hid), None, None
-        loss, logits, n_ok = ops.link_ce(hid, last.weight, last.bias, golden)
+            return ops.linear(hid, weight, bias), None, None
+        loss, logits, n_ok = ops.link_ce(hid, weight, bias, golden)
         return logits, loss, n_ok
 
     def forward(self, x, x_pieces, x_pos, edge_index, edge_attr, pieces, conds, edge_select, golden_edge,

@@ -285,9 +285,21 @@ class _EmbedAtom(Function):
     def backward(ctx, g):
         x, xp, xq = ctx.saved_tensors
         g2 = g if (g.dtype == torch.float32 and g.is_contiguous()) else g.float().contiguous()
-        ga, gp, gq = (torch.zeros(s, dtype=torch.float32, device=g2.device) for s in ctx.shapes)
-        hip.embed_atom_bwd(x, xp, xq, g2, ga, gp, gq)
-        return None, None, None, ga, gp, gq
+        (na, da), (npc, dp), (nq, dq) = ctx.shapes
+        V, D = g2.shape
+        rows = (na + npc + nq + 3) // 4 * 4
+        if rows > 1024 or V == 0:
+            # large vocabularies: float atomics into zero-filled tables
+            ga, gp, gq = (torch.zeros(s, dtype=torch.float32, device=g2.device) for s in ctx.shapes)
+            hip.embed_atom_bwd(x, xp, xq, g2, ga, gp, gq)
+            return None, None, None, ga, gp, gq
+        # deterministic: indicator^T g on the GEMM, table gradients = its diagonal blocks
+        onehot = torch.empty(V, rows, dtype=torch.float32, device=g2.device)
+        hip.embed_atom_onehot(x, xp, xq, na, npc, nq, onehot)
+        full = torch.empty(rows, D, dtype=torch.float32, device=g2.device)
+        hip.gemm(rows, D, V, onehot, 1, rows, g2, D, 1, full, D, split_k=0)
+        return (None, None, None, full[:na, :da], full[na:na + npc, da:da + dp],
+                full[na + npc:na + npc + nq, da + dp:])
 
 
 def embed_atom(x, xp, xq, e_atom, e_piece, e_pos):
