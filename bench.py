@@ -35,6 +35,7 @@ def parse():
     ap.add_argument('--batch', type=int, default=4096, help='molecules per GPU per step')
     ap.add_argument('--dataset', type=int, default=0, help='synthetic molecules per rank (default 4x batch)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--gemm-shapes', action='store_true', help='per-shape GEMM timing table on stderr')
     ap.add_argument('--cpu-batch', type=int, default=256)
     ap.add_argument('--cpu-steps', type=int, default=3)
     return ap.parse_args()
@@ -173,6 +174,10 @@ def main():
             'rec_loss_last_step': round(final_loss, 5),
         }
         out.update(hip.roofline_report(prof, HBM_PEAK_GBS, MFMA_F32_PEAK_TFLOPS))
+        if args.gemm_shapes:
+            print('M N K A-contig B-contig masked rowsum launches ms TFLOP/s', file=sys.stderr)
+            for row in hip.gemm_shape_table(prof):
+                print(' '.join(str(v) for v in row), file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(tok, args.cpu_batch, args.cpu_steps)
         print(json.dumps(out), flush=True)

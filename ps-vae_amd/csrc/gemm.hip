@@ -26,6 +26,13 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifdef PSVAE_EXP_CLOCK   // diagnostic build only: cycle / wall-clock stamps around the k loop
+__device__ unsigned long long psvae_exp_stamps[8 * 8192];
+extern "C" int psvae_exp_read_stamps(unsigned long long *host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(psvae_exp_stamps), sizeof(unsigned long long) * n);
+}
+#endif
+
 namespace {
 
 constexpr int THREADS = 256;
@@ -176,6 +183,10 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_panel_kernel(GemmArgs g) {
     __shared__ __align__(16) float smem[LDS_FLOATS];
     float *As = smem, *Bs = smem + A_FLOATS;
 
+#ifdef PSVAE_EXP_CLOCK
+    const unsigned long long exp_r_entry = __builtin_amdgcn_s_memrealtime();
+    unsigned long long exp_r_first = 0;
+#endif
     int tile_m, tile_n, z;
     if (!tile_of_block(g, tile_m, tile_n, z)) return;
     const int m0 = tile_m * BM, n0 = tile_n * g.bn;
@@ -199,6 +210,9 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_panel_kernel(GemmArgs g) {
     }
     const float *a_rd = As + lhi * LA::STRIDE + wave * 32 + l31;
     const float *b_rd = Bs + lhi * LB::STRIDE + l31;
+#ifdef PSVAE_EXP_CLOCK
+    const unsigned long long exp_t0 = __builtin_amdgcn_s_memtime(), exp_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int k0 = k_begin; k0 < k_end; k0 += BK) {
 #ifdef PSVAE_EXP_NOSTORE   // timing experiment only: wrong results
         if (k0 == k_begin) {
@@ -206,6 +220,9 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_panel_kernel(GemmArgs g) {
         LA::template store<MASK, false>(As, ra, rma, m0, k0, g.M, k_end, -1, tid);
         LB::template store<false, ONES>(Bs, rb, rmb, n0, k0, n_lim, k_end, ones_x, tid);
         __syncthreads();
+#ifdef PSVAE_EXP_CLOCK
+        if (k0 == k_begin) exp_r_first = __builtin_amdgcn_s_memrealtime();
+#endif
 #ifdef PSVAE_EXP_NOSTORE
         }
 #endif
@@ -222,8 +239,10 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_panel_kernel(GemmArgs g) {
         float a_cur = a_rd[0], b_cur[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j) b_cur[j] = b_rd[j * 32];
+        const int k_live = k_end - k0;   // the last k-tile of a chunk may be partly empty
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
+            if (kk > 0 && kk >= k_live) break;   // wave-uniform
             float a_nxt = 0.f, b_nxt[TN];
             if (kk + 2 < BK) {
                 a_nxt = a_rd[(kk + 2) * LA::STRIDE];
@@ -246,6 +265,9 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_panel_kernel(GemmArgs g) {
 #endif
     }
 
+#ifdef PSVAE_EXP_CLOCK
+    const unsigned long long exp_t1 = __builtin_amdgcn_s_memtime(), exp_r1 = __builtin_amdgcn_s_memrealtime();
+#endif
     // Epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) +
     // 4 * (lane >> 5): a direct store would be 16 dword stores per tile, each touching two
     // 128-B row segments.  Instead every wave transposes one tile at a time through its own
@@ -307,6 +329,17 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_panel_kernel(GemmArgs g) {
             }
         }
     }
+#ifdef PSVAE_EXP_CLOCK
+    if (tid == 0 && blockIdx.x < 8192) {
+        const unsigned long long r2 = __builtin_amdgcn_s_memrealtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long r3 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long *d = psvae_exp_stamps + 8 * blockIdx.x;
+        d[0] = exp_r_entry, d[1] = exp_r0, d[2] = exp_r_first, d[3] = exp_r1, d[4] = r2, d[5] = r3;
+        d[6] = exp_t1 - exp_t0;
+        d[7] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -409,12 +442,21 @@ __global__ void gemm_splitk_reduce_kernel(GemmArgs g) {
     }
 }
 
+// diagnostic knob: extra dynamic LDS per workgroup lowers the number of resident workgroups
+static size_t exp_dyn_lds() {
+    static const size_t v = [] {
+        const char *e = getenv("PSVAE_GEMM_PAD_LDS");
+        return e ? (size_t)atoi(e) : (size_t)0;
+    }();
+    return v;
+}
+
 template <int TN, int BK>
 void launch_panel(const GemmArgs &g, bool a_kc, bool b_kc, dim3 grid, hipStream_t s) {
     const bool mask = g.amask != nullptr, ones = g.rowsum != nullptr;
     const dim3 blk(THREADS);
 #define PSVAE_PANEL(AKC, BKC, MASK, ONES) \
-    hipLaunchKernelGGL((gemm_panel_kernel<TN, BK, AKC, BKC, MASK, ONES>), grid, blk, 0, s, g)
+    hipLaunchKernelGGL((gemm_panel_kernel<TN, BK, AKC, BKC, MASK, ONES>), grid, blk, exp_dyn_lds(), s, g)
     if (a_kc && b_kc) {                 // forward X W^T
         if (mask) PSVAE_PANEL(true, true, true, false); else PSVAE_PANEL(true, true, false, false);
     } else if (a_kc) {                  // input gradient dY W
@@ -457,16 +499,17 @@ void panel_shape(int n_ext, int &nc, int &bn, int &tn) {
         }
 }
 
-// split_k == 0: pick a split that fills the chip when the output has few row panels and K is
-// long (the weight-gradient products: M, N ~ 300, K = number of rows in the batch).
+// split_k == 0: pick a split that fills the chip when the output has few tiles: the
+// weight-gradient products (M, N ~ 300, K = number of rows in the batch) and the per-step
+// products of the GRU (4096 rows, K = 600).
 int resolve_split(int M, int N, int K, int split_k) {
     if (split_k >= 1) return split_k;
     int nc, bn, tn;
     panel_shape(N + 1, nc, bn, tn);
     const long long tiles = (long long)psvae_cdiv(M, 128) * nc;
-    if (tiles >= 192 || K <= 2048) return 1;
+    if (tiles >= 192) return 1;
     long long s = 512 / tiles;
-    const long long by_k = K / 256;
+    const long long by_k = K / 128;   // at least four k-tiles of work per split
     if (s > by_k) s = by_k;
     return s < 1 ? 1 : (int)s;
 }

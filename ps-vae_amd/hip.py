@@ -123,10 +123,10 @@ PROFILE = None
 
 
 class _Prof:
-    __slots__ = ('name', 'work', 'e0')
+    __slots__ = ('name', 'work', 'e0', 'tag')
 
-    def __init__(self, name, work):
-        self.name, self.work, self.e0 = name, work, None
+    def __init__(self, name, work, tag=None):
+        self.name, self.work, self.e0, self.tag = name, work, None, tag
 
     def __enter__(self):
         if PROFILE is not None:
@@ -137,7 +137,7 @@ class _Prof:
         if self.e0 is not None and PROFILE is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            PROFILE.setdefault(self.name, []).append((self.e0, e1, self.work))
+            PROFILE.setdefault(self.name, []).append((self.e0, e1, self.work, self.tag))
 
 
 def aggregate_bytes(V, E, H, backward=False):
@@ -147,13 +147,27 @@ def aggregate_bytes(V, E, H, backward=False):
     return E * (4 * H + 5) + V * (8 * H + 4) + (V * 4 * H if backward else 0)
 
 
+def gemm_shape_table(prof):
+    """Per GEMM shape: [M, N, K, A contiguous along, B contiguous along, masked, rowsum,
+    launches, total ms, TFLOP/s], slowest first (call after a device synchronise)."""
+    acc = {}
+    for it in prof.get('gemm_f32_kernel', []):
+        a = acc.setdefault(it[3], [0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += it[0].elapsed_time(it[1])
+        a[2] += it[2]
+    rows = [list(k) + [v[0], round(v[1], 3), round(v[2] / (v[1] * 1e-3) / 1e12, 1) if v[1] > 0 else 0.0]
+            for k, v in acc.items()]
+    return sorted(rows, key=lambda r: -r[8])
+
+
 def roofline_report(prof, hbm_peak_gbs, mfma_peak_tflops):
     """Summarise a PROFILE dict (call after a device synchronise)."""
     torch.cuda.synchronize()
     groups = {}
     for name, items in prof.items():
-        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in items)
-        groups[name] = {'launches': len(items), 'ms': ms, 'work': sum(w for _, _, w in items)}
+        ms = sum(it[0].elapsed_time(it[1]) for it in items)
+        groups[name] = {'launches': len(items), 'ms': ms, 'work': sum(it[2] for it in items)}
     out = {}
 
     def entry(name, bound):
@@ -192,7 +206,10 @@ def gemm(M, N, K, A, sa_m, sa_k, B, sb_k, sb_n, C, ldc, bias=None, relu=False, a
     L = lib()
     nbytes = L.psvae_gemm_f32_workspace_bytes(M, N, K, split_k)
     ws = workspace(nbytes, C.device) if nbytes else None
-    with _Prof('gemm_f32_kernel', 2.0 * M * N * K):
+    tag = None
+    if PROFILE is not None:
+        tag = (M, N, K, 'k' if sa_k == 1 else 'm', 'k' if sb_k == 1 else 'n', amask is not None, rowsum is not None)
+    with _Prof('gemm_f32_kernel', 2.0 * M * N * K, tag):
         rc = L.psvae_gemm_f32(M, N, K, ptr(A, torch.float32), ptr(amask, torch.float32), sa_m, sa_k,
                               ptr(B, torch.float32), sb_k, sb_n, ptr(C, torch.float32), ldc,
                               ptr(bias, torch.float32), ptr(rowsum, torch.float32), 1 if relu else 0,

@@ -477,12 +477,12 @@ class _LinkCe(Function):
         if want_gb:
             gb = torch.zeros(C, dtype=torch.float32, device=w.device)
         if ctx.needs_input_grad[1]:
-            gw = torch.zeros(C, F, dtype=torch.float32, device=w.device)
+            # (dW)^T = hid^T dlogits: F rows fill the 128-row panels, the few classes are columns
+            gwt = torch.zeros(F, C, dtype=torch.float32, device=w.device)
             if P:
-                hip.gemm(C, F, P, dlogits, 1, C, hid2, _ld(hid2), 1, gw, F, split_k=0,
-                         rowsum=gb if want_gb else None)
-            gw = gw * g_loss
-        elif want_gb and P:
+                hip.gemm(F, C, P, hid2, 1, _ld(hid2), dlogits, C, 1, gwt, C, split_k=0)
+            gw = gwt.t() * g_loss
+        if want_gb and P:
             hip.colsum(dlogits, gb)
         if want_gb:
             gb = gb * g_loss
