@@ -89,6 +89,18 @@ def cpu_baseline(tok, batch, steps):
             'model_step_molecules_per_s': round(batch * steps / t_model, 2)}
 
 
+def pmc_traffic():
+    """HBM bytes per launch from the newest committed counter pass (profiles/*_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this same command, corrected as
+    tools/pmc_traffic.py documents); None when no such file travels with the tree."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', '*_traffic.json')))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        return json.load(f)
+
+
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -173,7 +185,7 @@ def main():
                        'atoms_per_step': stats['V'] // args.steps, 'pairs_per_step': stats['P'] // args.steps},
             'rec_loss_last_step': round(final_loss, 5),
         }
-        out.update(hip.roofline_report(prof, HBM_PEAK_GBS, MFMA_F32_PEAK_TFLOPS))
+        out.update(hip.roofline_report(prof, HBM_PEAK_GBS, MFMA_F32_PEAK_TFLOPS, pmc_traffic()))
         if args.gemm_shapes:
             print('M N K A-contig B-contig masked rowsum launches ms TFLOP/s', file=sys.stderr)
             for row in hip.gemm_shape_table(prof):

@@ -161,8 +161,9 @@ def gemm_shape_table(prof):
     return sorted(rows, key=lambda r: -r[8])
 
 
-def roofline_report(prof, hbm_peak_gbs, mfma_peak_tflops):
-    """Summarise a PROFILE dict (call after a device synchronise)."""
+def roofline_report(prof, hbm_peak_gbs, mfma_peak_tflops, traffic=None):
+    """Summarise a PROFILE dict (call after a device synchronise).  `traffic`: optional
+    {kernel group: {'hbm_bytes_per_launch': ...}} from a separate counter pass."""
     torch.cuda.synchronize()
     groups = {}
     for name, items in prof.items():
@@ -179,7 +180,8 @@ def roofline_report(prof, hbm_peak_gbs, mfma_peak_tflops):
         else:
             ach, peak, unit = g['work'] / (g['ms'] * 1e-3) / 1e9, hbm_peak_gbs, 'GB/s'
         return {'kernel': name, 'bound': bound, 'achieved': round(ach, 2), 'peak': peak, 'unit': unit,
-                'frac': round(ach / peak, 4), 'traffic': None, 'launches': g['launches'],
+                'frac': round(ach / peak, 4),
+                'traffic': (traffic or {}).get(name, {}).get('hbm_bytes_per_launch'), 'launches': g['launches'],
                 'avg_launch_us': round(g['ms'] * 1e3 / g['launches'], 2),
                 'work_per_launch': round(g['work'] / g['launches'], 1)}
 

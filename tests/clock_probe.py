@@ -13,13 +13,21 @@ import ps_vae_amd  # noqa: E402,F401
 from ps_vae_amd import hip  # noqa: E402
 
 M, K, N = (int(a) for a in sys.argv[1:4])
-secs = float(sys.argv[4]) if len(sys.argv) > 4 else 2.0
+mode = sys.argv[4] if len(sys.argv) > 4 else 'fwd'
+secs = float(sys.argv[5]) if len(sys.argv) > 5 else 2.0
 dev = torch.device('cuda:0')
 x = torch.randn(M, K, device=dev)
 w = torch.randn(N, K, device=dev) * 0.05
 b = torch.randn(N, device=dev)
 y = torch.empty(M, N, device=dev)
-fn = lambda: hip.gemm(M, N, K, x, K, 1, w, 1, K, y, N, bias=b, relu=True)
+gy = torch.randn(M, N, device=dev)
+gx = torch.empty(M, K, device=dev)
+gw = torch.empty(N, K, device=dev)
+gb = torch.empty(N, device=dev)
+fn = {'fwd': lambda: hip.gemm(M, N, K, x, K, 1, w, 1, K, y, N, bias=b, relu=True),
+      'dx': lambda: hip.gemm(M, K, N, gy, N, 1, w, K, 1, gx, K),
+      'dxm': lambda: hip.gemm(M, K, N, gy, N, 1, w, K, 1, gx, K, amask=y),
+      'dw': lambda: hip.gemm(N, K, M, gy, 1, N, x, K, 1, gw, K, split_k=0, rowsum=gb)}[mode]
 fn()
 torch.cuda.synchronize()
 t0 = time.time()
@@ -33,10 +41,12 @@ el = time.time() - t0
 print(f'{n} launches, {el / n * 1e6:.1f} us each, {2.0 * M * N * K * n / el / 1e12:.1f} TFLOP/s')
 L = hip.lib()
 L.psvae_exp_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
-nb = min(8192, ((M + 127) // 128) * ((N + 159) // 160))
 buf = np.zeros(8 * 8192, dtype=np.uint64)
 rc = L.psvae_exp_read_stamps(buf.ctypes.data, 8 * 8192)
-s = buf.reshape(-1, 8)[:nb]
+s = buf.reshape(-1, 8)
+s = s[s[:, 0] > 0]
+s = s[s[:, 0] + np.uint64(100000) > s[:, 0].max()]   # the last launch only
+nb = len(s)
 t = s[:, :6].astype(np.float64)
 t0 = t[:, 0].min()
 t = (t - t0) / 100.0   # us since the first block entered
