@@ -10,6 +10,7 @@ BASELINE.json configs[2] ("synthetic ZINC-shaped graphs, batch 4096") per GPU, w
 Rank 0 prints ONE JSON line (see README / DESIGN.md for the fields).
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -150,12 +151,18 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # a full collection over the interpreter's ~1e6 module objects costs ~100 ms; take it now
+    # and freeze the survivors so that it cannot land inside the timed region
+    gc.collect()
+    gc.freeze()
     hip.PROFILE = {}
     fence()
     t0 = time.perf_counter()
     stats = {'V': 0, 'E': 0, 'Ein': 0, 'P': 0}
+    trace = []
     for _ in range(args.steps):
         b = step()
+        trace.append(time.perf_counter())
         c = b.compact
         stats['V'] += c.num_nodes
         stats['E'] += c.csr.col.numel()
@@ -163,6 +170,9 @@ def main():
         stats['P'] += len(c.pairs)
     fence()
     elapsed = time.perf_counter() - t0
+    if os.environ.get('PSVAE_BENCH_TRACE'):
+        print('host ms per step (no sync):', [round((b - a) * 1e3, 1) for a, b in zip([t0] + trace[:-1], trace)],
+              'final fence ms', round((t0 + elapsed - trace[-1]) * 1e3, 1), file=sys.stderr)
     prof, hip.PROFILE = hip.PROFILE, None
     final_loss = float(model.logged['reconstruct loss'].detach())
     if world > 1:

@@ -105,9 +105,9 @@ _workspaces = {}
 
 
 def workspace(nbytes, device):
-    """A per-device scratch buffer, grown on demand.  All users enqueue on PyTorch's current
-    stream, so successive kernels that reuse it are ordered."""
-    key = (device.type, device.index)
+    """A scratch buffer per (device, stream), grown on demand.  Kernels that reuse it are
+    ordered by the stream they are enqueued on; two streams never share one."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)

@@ -16,6 +16,9 @@ from .common_nn import MLP, run_linear, run_sequential
 from .encoder import Encoder
 
 
+_SIDE_STREAMS = {}   # one extra stream per device, shared by every decoder instance
+
+
 class VAEPieceDecoder(nn.Module):
     def __init__(self, atom_embedding_dim, piece_embedding_dim, max_pos, pos_embedding_dim, piece_hidden_dim,
                  node_hidden_dim, num_edge_type, cond_dim, latent_dim, tokenizer, t=4):
@@ -90,8 +93,21 @@ class VAEPieceDecoder(nn.Module):
         loss, logits, n_ok = ops.link_ce(hid, weight, bias, golden)
         return logits, loss, n_ok
 
+    def embed_nodes_async(self, node_x, csr):
+        """Message passing over the in-piece bonds (:96) on a side stream; returns a handle
+        for forward(node_embedding=...), which joins the streams before the first use."""
+        main = torch.cuda.current_stream(node_x.device)
+        side = _SIDE_STREAMS.get(node_x.device)
+        if side is None:
+            side = _SIDE_STREAMS[node_x.device] = torch.cuda.Stream(node_x.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            node_embedding, _ = self.graph_embedding.embed_node(node_x, csr, None)
+        node_x.record_stream(side)
+        return node_embedding, side
+
     def forward(self, x, x_pieces, x_pos, edge_index, edge_attr, pieces, conds, edge_select, golden_edge,
-                return_accu=False, eps=None):
+                return_accu=False, eps=None, node_embedding=None):
         """:71-126.  Accepts the reference's tensors (x [B,N,D], edge_index/edge_attr of the
         in-piece edges, edge_select [B,N,N] bool, golden_edge [P] int64) or the compact
         containers (x [V,D], edge_index = ops.Csr, edge_select = ops.PairList)."""
@@ -99,9 +115,15 @@ class VAEPieceDecoder(nn.Module):
         gold_piece = pieces[:, 1:].flatten()
         output = self.piece_logits(z_vecs, pieces)
 
-        node_dim = x.shape[-1]
-        node_x = x.reshape(-1, node_dim)
-        node_embedding, _ = self.graph_embedding.embed_node(node_x, edge_index, edge_attr)
+        if node_embedding is not None:
+            node_embedding, side = node_embedding
+            main = torch.cuda.current_stream(node_embedding.device)
+            main.wait_stream(side)
+            node_embedding.record_stream(main)
+        else:
+            node_dim = x.shape[-1]
+            node_x = x.reshape(-1, node_dim)
+            node_embedding, _ = self.graph_embedding.embed_node(node_x, edge_index, edge_attr)
         pairs = edge_select if isinstance(edge_select, ops.PairList) else ops.PairList.from_edge_select(edge_select)
         golden = golden_edge if golden_edge.dtype == torch.int32 else golden_edge.to(torch.int32)
         pred_edge, edge_loss, n_ok = self.link_logits(node_embedding, z_vecs, pairs, golden)

@@ -7,6 +7,7 @@ validation_step, test_step, configure_optimizers, plus global_step / log.
 forward() takes either the reference's batch dict (any source) or a CollatedBatch whose
 `.compact` layout is present; in the second case no index preparation happens on the way:
 the kernels read the CSR / pair lists collation wrote."""
+import os
 import time
 
 import torch
@@ -33,6 +34,8 @@ class PSVAEModel(nn.Module):
         self.total_time = 0
         self.global_step = 0
         self.logged = {}
+        # compact path only; PSVAE_STREAMS=1 keeps everything on the current stream
+        self.two_streams = os.environ.get('PSVAE_STREAMS', '2') != '1'
 
     @property
     def device(self):
@@ -45,12 +48,18 @@ class PSVAEModel(nn.Module):
         compact = getattr(batch, 'compact', None)
         if compact is not None:
             x = self.decoder.embed_atom(compact.cx, compact.cxp, compact.cxpos)          # [V, D]
+            # The decoder's message passing over the in-piece bonds depends only on x: it runs on
+            # a second stream beside the encoder (and so does its backward), so that one
+            # chain's HBM-bound aggregations and tile write-outs fill the gaps of the other's
+            # matrix products.
+            node_embedding = self.decoder.embed_nodes_async(x, compact.csr_in) if self.two_streams else None
             _, all_x = self.encoder.embed_node(x, compact.csr)
             graph_embedding = self.encoder.embed_graph(all_x, compact.segments)
             batch_size = compact.num_graphs
             z, res = self.decoder(x=x, x_pieces=None, x_pos=None, edge_index=compact.csr_in, edge_attr=None,
                                   pieces=batch.pieces, conds=graph_embedding, edge_select=compact.pairs,
-                                  golden_edge=compact.golden, return_accu=return_accu, eps=eps)
+                                  golden_edge=compact.golden, return_accu=return_accu, eps=eps,
+                                  node_embedding=node_embedding)
             props = batch.props
         else:
             x, edge_index, edge_attr = batch['x'], batch['edge_index'], batch['edge_attr']
