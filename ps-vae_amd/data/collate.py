@@ -4,7 +4,8 @@ Replaces the DataLoader's __getitem__ + collate_fn of the reference
 (src/data/bpe_dataset.py:56-155, 173-181).  The host only prefix-sums per-molecule counts
 (a few numpy cumsums over the batch); all per-atom / per-cell work runs in
 psvae_collate_count / psvae_collate_fill.  One device->host read per batch returns P, the
-number of kept candidate pairs, which sizes golden_edge exactly as the reference does.
+number of kept candidate pairs, which sizes golden_edge exactly as the reference does (in the
+compact-only layout it is read late, off the critical path).
 """
 import numpy as np
 import torch
@@ -15,21 +16,63 @@ KEEP_PROB = 0.022   # src/data/bpe_dataset.py:129
 
 
 class CompactBatch:
-    """Real atoms only; node id = node_off[b] + m.  See include/psvae_hip.h (psvae_collate_fill)."""
+    """Real atoms only; node id = node_off[b] + m.  See include/psvae_hip.h (psvae_collate_fill).
 
-    def __init__(self, t, node_off, pair_off, num_graphs):
+    `pairs` / `golden` may be backed by buffers sized to an upper bound of P: the exact count
+    is then read from the device (one int32, copied asynchronously during collation) the first
+    time either is touched, which is after the encoder has been enqueued."""
+
+    def __init__(self, t, node_off, pair_off, num_graphs, pending=None):
         self.cx, self.cxp, self.cxpos = t['cx'], t['cxp'], t['cxpos']
         self.node_off, self.pair_off = node_off, pair_off
         self.csr = ops.Csr(t['row_ptr'], t['col'], t['cls'])
         self.csr_in = ops.Csr(t['in_row_ptr'], t['in_col'], t['in_cls'])
         self.segments = ops.Segments.from_offsets(node_off)
-        self.pairs = ops.PairList(t['pair_src'], t['pair_dst'], t['pair_graph'], pair_off, self.segments)
-        self.golden = t['golden32']
+        self._pair_bufs = (t['pair_src'], t['pair_dst'], t['pair_graph'], t['golden32'])
+        self._pending = pending          # (event, pinned int32[1]) while P is still on its way
+        self._pairs = self._golden = None
         self.num_graphs = num_graphs
+        if pending is None:
+            self._resolve(t['pair_src'].numel())
+
+    def _resolve(self, P=None):
+        if self._pairs is None:
+            if P is None:
+                event, host = self._pending
+                event.synchronize()
+                P = int(host[0])
+                self._pending = None
+            src, dst, graph, gold = (b[:P] for b in self._pair_bufs)
+            self._pairs = ops.PairList(src, dst, graph, self.pair_off, self.segments)
+            self._golden = gold
+
+    @property
+    def pairs(self):
+        self._resolve()
+        return self._pairs
+
+    @property
+    def golden(self):
+        self._resolve()
+        return self._golden
 
     @property
     def num_nodes(self):
         return self.cx.numel()
+
+
+_PINNED = {'ring': [], 'next': 0}
+
+
+def _pinned_int():
+    """One of a small ring of pinned int32[1] host buffers (a batch holds its buffer only
+    until the pair count has been read, long before the ring wraps)."""
+    ring = _PINNED['ring']
+    if len(ring) < 16:
+        ring.append(torch.empty(1, dtype=torch.int32).pin_memory())
+        return ring[-1]
+    _PINNED['next'] = (_PINNED['next'] + 1) % len(ring)
+    return ring[_PINNED['next']]
 
 
 class CollatedBatch(dict):
@@ -82,7 +125,19 @@ def collate_packed(dpacked, ids, uniforms=None, atom_pad=10, piece_pad=300, num_
     pair_cnt = torch.empty(max(B, 1), dtype=torch.int32, device=dev)
     pair_off = torch.empty(B + 1, dtype=torch.int32, device=dev)
     hip.collate_count(B, N, mol_ids, dpacked, rng_off, uniforms, keep_prob, pair_cnt, pair_off)
-    P = int(pair_off[B].item())          # the one device->host read of collation
+    pending = None
+    if reference_layout or not compact_layout:
+        P = int(pair_off[B].item())      # golden_edge is sized exactly, as the reference's is
+    else:
+        # compact layout only: the pair outputs are sized to a bound known on the host (every
+        # drawn uniform kept + every bonded cross-piece cell) and the exact count follows
+        # asynchronously, so the host does not stop here
+        P = R + (E - Ein)
+        host_p = _pinned_int()
+        host_p.copy_(pair_off[B:B + 1], non_blocking=True)
+        event = torch.cuda.Event()
+        event.record()
+        pending = (event, host_p)
 
     i32, i64, u8 = torch.int32, torch.int64, torch.uint8
 
@@ -141,5 +196,5 @@ def collate_packed(dpacked, ids, uniforms=None, atom_pad=10, piece_pad=300, num_
     out.pieces, out.props, out.batch_size = ref['pieces'], ref['props'], B
     out.num_uniforms = R
     if compact_layout:
-        out.compact = CompactBatch(cmp_, node_off, pair_off, B)
+        out.compact = CompactBatch(cmp_, node_off, pair_off, B, pending)
     return out
