@@ -57,6 +57,7 @@ struct GemmArgs {
     int ws_ld;            // n_ext rounded up to a multiple of 4
     int c_vec;            // C (and ws) rows may be written 16 bytes at a time
     int nt_m, nt_n, bn;   // tiles and column-tile width
+    int wn;               // wave grid of the panel kernel: 1 = 4 x 1, 2 = 2 x 2
 };
 
 __device__ __forceinline__ void epilogue_store(const GemmArgs &g, int row, int col, float v) {
@@ -172,9 +173,11 @@ struct TileLoader {
     }
 };
 
-template <int TN, int BK, bool A_KC, bool B_KC, bool MASK, bool ONES>
+// WN = 1: the 4 waves stack along M (128-row panel, 32*TN columns).  WN = 2: a 2 x 2 wave grid
+// (64 rows x 64*TN columns), for products whose M fits 64-row panels with less padding.
+template <int TN, int BK, bool A_KC, bool B_KC, bool MASK, bool ONES, int WN = 1>
 __global__ __launch_bounds__(THREADS, 2) void gemm_panel_kernel(GemmArgs g) {
-    constexpr int BM = 128, BN = 32 * TN;
+    constexpr int WM = 4 / WN, BM = 32 * WM, BN = 32 * TN * WN;
     using LA = TileLoader<BM, BK, A_KC>;
     using LB = TileLoader<BN, BK, B_KC>;
     constexpr int A_FLOATS = BK * LA::STRIDE, B_FLOATS = BK * LB::STRIDE;
@@ -193,6 +196,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_panel_kernel(GemmArgs g) {
     const int k_begin = z * g.k_chunk;
     const int k_end = min(g.K, k_begin + g.k_chunk);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_m = wave % WM, wave_n = wave / WM;
     const int l31 = lane & 31, lhi = lane >> 5;
     const int ones_x = g.N;
     const int n_lim = min(g.N, n0 + g.bn);   // columns of B this tile may read
@@ -208,8 +212,8 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_panel_kernel(GemmArgs g) {
         LA::template load<MASK>(ra, rma, g.A, g.amask, g.sa_m, g.sa_k, m0, k_begin, g.M, k_end, tid);
         LB::template load<false>(rb, rmb, g.B, nullptr, g.sb_n, g.sb_k, n0, k_begin, n_lim, k_end, tid);
     }
-    const float *a_rd = As + lhi * LA::STRIDE + wave * 32 + l31;
-    const float *b_rd = Bs + lhi * LB::STRIDE + l31;
+    const float *a_rd = As + lhi * LA::STRIDE + wave_m * 32 + l31;
+    const float *b_rd = Bs + lhi * LB::STRIDE + wave_n * TN * 32 + l31;
 #ifdef PSVAE_EXP_CLOCK
     const unsigned long long exp_t0 = __builtin_amdgcn_s_memtime(), exp_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -281,7 +285,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_panel_kernel(GemmArgs g) {
         const int prow = lane >> 3, pc4 = (lane & 7) * 4;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int cbase = n0 + j * 32;
+            const int cbase = n0 + (wave_n * TN + j) * 32;
             if (cbase >= col_lim) continue;   // wave-uniform
 #pragma unroll
             for (int r = 0; r < 16; ++r)
@@ -292,7 +296,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_panel_kernel(GemmArgs g) {
             if (!split && g.bias && col < g.N) bias4 = *reinterpret_cast<const float4 *>(g.bias + col);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int row = m0 + wave * 32 + prow + 8 * i;
+                const int row = m0 + wave_m * 32 + prow + 8 * i;
                 float4 v = *reinterpret_cast<const float4 *>(patch + (prow + 8 * i) * EPI_STRIDE + pc4);
 #ifdef PSVAE_EXP_NOEPI   // timing experiment only
                 if (v.x != 12345.678f) continue;
@@ -318,10 +322,10 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_panel_kernel(GemmArgs g) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // patch is rewritten by the next tile
         }
     } else {
-        const int row0 = m0 + wave * 32 + 4 * lhi;
+        const int row0 = m0 + wave_m * 32 + 4 * lhi;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int col = n0 + j * 32 + l31;
+            const int col = n0 + (wave_n * TN + j) * 32 + l31;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = row0 + (r & 3) + 8 * (r >> 2);
@@ -463,6 +467,16 @@ void launch_panel(const GemmArgs &g, bool a_kc, bool b_kc, dim3 grid, hipStream_
         if (mask) PSVAE_PANEL(true, false, true, false); else PSVAE_PANEL(true, false, false, false);
     } else if (b_kc) {
         if (mask) PSVAE_PANEL(false, true, true, false); else PSVAE_PANEL(false, true, false, false);
+    } else if (g.wn == 2) {             // the same on the 2 x 2 wave grid (TN == 5 only)
+        if constexpr (TN == 5) {
+#define PSVAE_PANEL22(MASK, ONES) \
+    hipLaunchKernelGGL((gemm_panel_kernel<5, BK, false, false, MASK, ONES, 2>), grid, blk, 0, s, g)
+            if (mask && ones) PSVAE_PANEL22(true, true);
+            else if (mask) PSVAE_PANEL22(true, false);
+            else if (ones) PSVAE_PANEL22(false, true);
+            else PSVAE_PANEL22(false, false);
+#undef PSVAE_PANEL22
+        }
     } else {                            // weight (+ bias) gradient dY^T [X | 1]
         if (mask && ones) PSVAE_PANEL(false, false, true, true);
         else if (mask) PSVAE_PANEL(false, false, true, false);
@@ -502,11 +516,19 @@ void panel_shape(int n_ext, int &nc, int &bn, int &tn) {
 // split_k == 0: pick a split that fills the chip when the output has few tiles: the
 // weight-gradient products (M, N ~ 300, K = number of rows in the batch) and the per-step
 // products of the GRU (4096 rows, K = 600).
+// The 2 x 2 wave grid (64-row panels, one column tile of 320) pays when it cuts the padded rows:
+// M = 300 is 5 panels of 64 instead of 3 of 128.
+bool prefer_2x2(int M, int n_ext) {
+    return n_ext > 224 && n_ext <= 320 && (M - 1) % 128 < 64;
+}
+
 int resolve_split(int M, int N, int K, int split_k) {
     if (split_k >= 1) return split_k;
     int nc, bn, tn;
     panel_shape(N + 1, nc, bn, tn);
-    const long long tiles = (long long)psvae_cdiv(M, 128) * nc;
+    // (assumes the strides of a weight-gradient product when the 2 x 2 grid could apply; a
+    // wrong guess only changes how many K chunks are cut)
+    const long long tiles = prefer_2x2(M, N + 1) ? psvae_cdiv(M, 64) : (long long)psvae_cdiv(M, 128) * nc;
     if (tiles >= 192) return 1;
     long long s = 512 / tiles;
     const long long by_k = K / 128;   // at least four k-tiles of work per split
@@ -567,7 +589,11 @@ extern "C" int psvae_gemm_f32(int M, int N, int K, const float *A, const float *
     if (panel) {
         int nc, bn, tn;
         panel_shape(g.n_ext, nc, bn, tn);
-        g.nt_m = psvae_cdiv(M, 128), g.nt_n = nc, g.bn = bn;
+        g.nt_m = psvae_cdiv(M, 128), g.nt_n = nc, g.bn = bn, g.wn = 1;
+        if (!a_kc && !b_kc && prefer_2x2(M, g.n_ext)) {
+            g.wn = 2, g.nt_m = psvae_cdiv(M, 64), g.nt_n = 1, g.bn = 320;
+            tn = 5;
+        }
         const long long blocks = (long long)psvae_cdiv((long long)g.nt_m * split_k, 8) * 8 * g.nt_n;
         PSVAE_REQUIRE(blocks < (1ll << 31), PSVAE_ETOOLARGE, "psvae_gemm_f32: grid too large");
         dim3 grid((unsigned)blocks);
