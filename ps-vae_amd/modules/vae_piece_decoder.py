@@ -113,13 +113,26 @@ class VAEPieceDecoder(nn.Module):
         containers (x [V,D], edge_index = ops.Csr, edge_select = ops.PairList)."""
         z_vecs, kl_loss = self.rsample(conds, eps)
         gold_piece = pieces[:, 1:].flatten()
-        output = self.piece_logits(z_vecs, pieces)
+        side = node_embedding[1] if node_embedding is not None else None
 
-        if node_embedding is not None:
-            node_embedding, side = node_embedding
-            main = torch.cuda.current_stream(node_embedding.device)
-            main.wait_stream(side)
+        def piece_branch():
+            output = self.piece_logits(z_vecs, pieces)
+            pred_piece = output.reshape(-1, output.shape[-1])
+            return pred_piece, self.piece_loss(pred_piece, gold_piece)
+
+        if side is not None:
+            # The piece language model (many small, latency-bound launches) shares the chip with
+            # the link predictor's large products: it continues on the side stream, behind the
+            # message passing that is already queued there.
+            main = torch.cuda.current_stream(z_vecs.device)
+            node_embedding = node_embedding[0]
+            main.wait_stream(side)                  # node_embedding is complete
             node_embedding.record_stream(main)
+            side.wait_stream(main)                  # z_vecs is complete
+            with torch.cuda.stream(side):
+                pred_piece, piece_loss = piece_branch()
+            for t in (z_vecs, pieces, gold_piece):
+                t.record_stream(side)
         else:
             node_dim = x.shape[-1]
             node_x = x.reshape(-1, node_dim)
@@ -128,8 +141,12 @@ class VAEPieceDecoder(nn.Module):
         golden = golden_edge if golden_edge.dtype == torch.int32 else golden_edge.to(torch.int32)
         pred_edge, edge_loss, n_ok = self.link_logits(node_embedding, z_vecs, pairs, golden)
 
-        pred_piece = output.reshape(-1, output.shape[-1])
-        piece_loss = self.piece_loss(pred_piece, gold_piece)
+        if side is not None:
+            main.wait_stream(side)
+            pred_piece.record_stream(main)
+            piece_loss.record_stream(main)
+        else:
+            pred_piece, piece_loss = piece_branch()
         rec_loss = piece_loss + edge_loss
         loss_tuple = (rec_loss, piece_loss, edge_loss, kl_loss)
         if return_accu:
