@@ -13,6 +13,8 @@
 // node range.  Each wave therefore reads whole contiguous row segments (16 B per lane).
 // Molecules are small and contiguous in node order, so the neighbour rows a block gathers
 // are the rows it (or the adjacent block) streams anyway: they are served by L1/L2.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -24,24 +26,69 @@ __device__ __forceinline__ float4 add4(float4 a, float4 b) {
     return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
 }
 
+// Index data of a block's node range, staged in LDS by one coalesced pass so that a lane's
+// neighbour-row loads do not wait behind two more dependent global loads (row_ptr, then col).
+// Blocks whose range holds more than STAGE_EDGES edges read the indices from global memory.
+constexpr int STAGE_NODES = 64, STAGE_EDGES = 768;
+
+struct StagedCsr {
+    int ptr[STAGE_NODES + 1];
+    int col[STAGE_EDGES];
+    unsigned char cls[STAGE_EDGES];
+};
+
+// returns true when the indices of nodes [begin, end) are in `sc` (edge ids relative to e_base)
+__device__ __forceinline__ bool stage_csr(StagedCsr &sc, int begin, int end, const int32_t *__restrict__ row_ptr,
+                                          const int32_t *__restrict__ col, const uint8_t *__restrict__ cls,
+                                          int &e_base) {
+    const int n = end - begin;
+    e_base = row_ptr[begin];
+    const int n_e = row_ptr[end] - e_base;
+    const bool ok = n <= STAGE_NODES && n_e <= STAGE_EDGES;   // block-uniform
+    if (ok) {
+        for (int i = threadIdx.x; i <= n; i += blockDim.x) sc.ptr[i] = row_ptr[begin + i] - e_base;
+        for (int e = threadIdx.x; e < n_e; e += blockDim.x) sc.col[e] = col[e_base + e], sc.cls[e] = cls[e_base + e];
+    }
+    __syncthreads();
+    return ok;
+}
+
 __global__ void gine_aggregate_fwd_kernel(int V, int cols, int slots, int nodes_per_block,
                                           const float4 *__restrict__ x, int ldx4,
                                           const float4 *__restrict__ table,
                                           const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
                                           const uint8_t *__restrict__ cls, float4 *__restrict__ out, int ldo4) {
+    __shared__ StagedCsr sc;
     const int c = threadIdx.x % cols, slot = threadIdx.x / cols;
-    if (slot >= slots) return;
     const int begin = blockIdx.x * nodes_per_block;
     const int end = min(V, begin + nodes_per_block);
+    int e_base;
+    const bool staged = stage_csr(sc, begin, end, row_ptr, col, cls, e_base);
+    if (slot >= slots) return;
     for (int i = begin + slot; i < end; i += slots) {
-        const int e0 = row_ptr[i], e1 = row_ptr[i + 1];
+        const int e0 = staged ? sc.ptr[i - begin] : row_ptr[i], e1 = staged ? sc.ptr[i - begin + 1] : row_ptr[i + 1];
+        const float4 self = x[(long long)i * ldx4 + c];
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int e = e0; e < e1; ++e) {
-            const float4 xj = x[(long long)col[e] * ldx4 + c];
-            const float4 t = table[(int)cls[e] * cols + c];
-            acc = add4(acc, relu_add(xj, t));
+        // atoms have at most a handful of bonds: four neighbour rows are requested at once
+        // (indices clamped, contributions predicated) instead of one dependent load at a time
+        for (int e = e0; e < e1; e += 4) {
+            int src[4], k[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ee = min(e + u, e1 - 1);
+                src[u] = staged ? sc.col[ee] : col[ee], k[u] = staged ? sc.cls[ee] : cls[ee];
+            }
+            float4 xj[4], t[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                xj[u] = x[(long long)src[u] * ldx4 + c];
+                t[u] = table[k[u] * cols + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (e + u < e1) acc = add4(acc, relu_add(xj[u], t[u]));
         }
-        out[(long long)i * ldo4 + c] = add4(acc, x[(long long)i * ldx4 + c]);
+        out[(long long)i * ldo4 + c] = add4(acc, self);
     }
 }
 
@@ -70,19 +117,34 @@ __global__ void gine_aggregate_bwd_kernel(int V, int C, int cols, int slots, int
             const float4 xj = x[(long long)j * ldx4 + c];
             float4 acc = g[(long long)j * ldg4 + c];
             const int e0 = t_row_ptr[j], e1 = t_row_ptr[j + 1];
-            for (int e = e0; e < e1; ++e) {
-                const int k = t_cls[e];
-                const float4 gd = g[(long long)t_col[e] * ldg4 + c];
-                const float4 t = table[k * cols + c];
-                float4 m;
-                m.x = xj.x + t.x > 0.f ? gd.x : 0.f;
-                m.y = xj.y + t.y > 0.f ? gd.y : 0.f;
-                m.z = xj.z + t.z > 0.f ? gd.z : 0.f;
-                m.w = xj.w + t.w > 0.f ? gd.w : 0.f;
-                acc = add4(acc, m);
+            for (int eb = e0; eb < e1; eb += 4) {   // four destination rows in flight, as in the forward
+                int dst[4], kc[4];
 #pragma unroll
-                for (int kk = 0; kk < MAXC; ++kk)
-                    if (kk == k) gt[kk] = add4(gt[kk], m);
+                for (int u = 0; u < 4; ++u) {
+                    const int ee = min(eb + u, e1 - 1);
+                    dst[u] = t_col[ee], kc[u] = t_cls[ee];
+                }
+                float4 gd4[4], t4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    gd4[u] = g[(long long)dst[u] * ldg4 + c];
+                    t4[u] = table[kc[u] * cols + c];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (eb + u >= e1) continue;
+                    const float4 gd = gd4[u], t = t4[u];
+                    const int k = kc[u];
+                    float4 m;
+                    m.x = xj.x + t.x > 0.f ? gd.x : 0.f;
+                    m.y = xj.y + t.y > 0.f ? gd.y : 0.f;
+                    m.z = xj.z + t.z > 0.f ? gd.z : 0.f;
+                    m.w = xj.w + t.w > 0.f ? gd.w : 0.f;
+                    acc = add4(acc, m);
+#pragma unroll
+                    for (int kk = 0; kk < MAXC; ++kk)
+                        if (kk == k) gt[kk] = add4(gt[kk], m);
+                }
             }
             if (add != nullptr) acc = add4(acc, add[(long long)j * ldadd4 + c]);
             g_x[(long long)j * ldgx4 + c] = acc;
@@ -102,22 +164,26 @@ __global__ void gine_aggregate_bwd_kernel(int V, int C, int cols, int slots, int
 }
 
 // g_table[i] (+)= sum over blocks b of partial[b][i] in a fixed order: a workgroup owns 32
-// consecutive outputs; 8 thread groups take blocks b = q, q+8, ...; their sums are added in
+// consecutive outputs; 32 thread groups take blocks b = q, q+32, ...; their sums are added in
 // q order.
-__global__ void gine_table_reduce_kernel(int n_out, int n_blocks, const float *__restrict__ partial,
-                                         float *__restrict__ g_table, int accumulate) {
-    __shared__ float sh[8][32];
+constexpr int REDUCE_GROUPS = 32;
+
+__global__ __launch_bounds__(32 * REDUCE_GROUPS) void gine_table_reduce_kernel(int n_out, int n_blocks,
+                                                                               const float *__restrict__ partial,
+                                                                               float *__restrict__ g_table,
+                                                                               int accumulate) {
+    __shared__ float sh[REDUCE_GROUPS][32];
     const int q = threadIdx.x >> 5, l = threadIdx.x & 31;
     const int i = blockIdx.x * 32 + l;
     float s = 0.f;
     if (i < n_out)
-        for (int b = q; b < n_blocks; b += 8) s += partial[(long long)b * n_out + i];
+        for (int b = q; b < n_blocks; b += REDUCE_GROUPS) s += partial[(long long)b * n_out + i];
     sh[q][l] = s;
     __syncthreads();
     if (q == 0 && i < n_out) {
         float t = sh[0][l];
 #pragma unroll
-        for (int k = 1; k < 8; ++k) t += sh[k][l];
+        for (int k = 1; k < REDUCE_GROUPS; ++k) t += sh[k][l];
         g_table[i] = accumulate ? g_table[i] + t : t;
     }
 }
@@ -140,7 +206,16 @@ Shape shape_for(int V, int H, int max_blocks) {
     return s;
 }
 
-constexpr int BWD_MAX_BLOCKS = 1024;
+// Most workgroups the backward is cut into (each writes one [C,H] slab of table-gradient
+// partials).  PSVAE_GINE_BWD_BLOCKS overrides it for tuning runs.
+int bwd_max_blocks() {
+    static const int v = [] {
+        const char *e = getenv("PSVAE_GINE_BWD_BLOCKS");
+        const int x = e ? atoi(e) : 1024;
+        return x < 1 ? 1 : x;
+    }();
+    return v;
+}
 
 int check_common(const char *fn, int V, int H, int C, const void *x, int ldx) {
     PSVAE_REQUIRE(V >= 0 && H > 0 && C > 0, PSVAE_EINVAL, "%s: bad sizes V=%d H=%d C=%d", fn, V, H, C);
@@ -172,7 +247,7 @@ extern "C" int psvae_gine_aggregate_fwd(int V, int H, int C, const float *x, int
 
 extern "C" size_t psvae_gine_aggregate_bwd_workspace_bytes(int V, int H, int C) {
     if (V <= 0 || H <= 0 || C <= 0) return 0;
-    const Shape s = shape_for(V, H, BWD_MAX_BLOCKS);
+    const Shape s = shape_for(V, H, bwd_max_blocks());
     return (size_t)s.blocks * C * H * sizeof(float);
 }
 
@@ -196,7 +271,7 @@ extern "C" int psvae_gine_aggregate_bwd(int V, int H, int C, const float *x, int
     PSVAE_REQUIRE(workspace && psvae_aligned16(workspace) &&
                       workspace_bytes >= psvae_gine_aggregate_bwd_workspace_bytes(V, H, C),
                   PSVAE_EWORKSPACE, "psvae_gine_aggregate_bwd: workspace too small");
-    const Shape s = shape_for(V, H, BWD_MAX_BLOCKS);
+    const Shape s = shape_for(V, H, bwd_max_blocks());
     const size_t lds = (size_t)s.slots * C * s.cols * sizeof(float4);
     PSVAE_REQUIRE(lds <= 64 * 1024, PSVAE_ETOOLARGE, "psvae_gine_aggregate_bwd: LDS need %zu", lds);
     if (C <= 4)
@@ -213,7 +288,7 @@ extern "C" int psvae_gine_aggregate_bwd(int V, int H, int C, const float *x, int
                            (float4 *)workspace);
     PSVAE_CHECK_LAUNCH("psvae_gine_aggregate_bwd");
     const int n_out = C * H;
-    hipLaunchKernelGGL(gine_table_reduce_kernel, dim3(psvae_cdiv(n_out, 32)), dim3(256), 0, s_, n_out, s.blocks,
+    hipLaunchKernelGGL(gine_table_reduce_kernel, dim3(psvae_cdiv(n_out, 32)), dim3(32 * REDUCE_GROUPS), 0, s_, n_out, s.blocks,
                        (const float *)workspace, g_table, accumulate_table);
     PSVAE_CHECK_LAUNCH("psvae_gine_aggregate_bwd (table reduce)");
     return PSVAE_OK;
