@@ -155,6 +155,9 @@ int psvae_gine_aggregate_bwd(int V, int H, int C, const float *x, int ldx, const
  * (src/modules/common_nn.py:8-23; forward X W^T, input gradient dY W, weight gradient
  * dY^T X) is one call.  amask (optional, addressed like A) gates A: A(m,k) counts as 0 where
  * amask(m,k) <= 0 — the ReLU derivative applied to a gradient operand as it is loaded.
+ * cmask (optional, [M,N] with the row stride of C) gates the result instead: C[m][n] = 0
+ * where cmask[m][n] <= 0 — the ReLU derivative applied once, as a gradient is produced, so that
+ * the products that consume it need no gate.
  * bias may be NULL.  rowsum (optional, [M]) receives sum_k A(m,k) (after the gate) — with
  * A = dY^T that is the bias gradient, computed in the same pass as the weight gradient.
  * accumulate != 0 adds to C (and rowsum).  split_k > 1 reduces partial products through
@@ -166,7 +169,8 @@ size_t psvae_gemm_f32_workspace_bytes(int M, int N, int K, int split_k);
 int psvae_gemm_f32(int M, int N, int K,
                    const float *A, const float *amask, int64_t sa_m, int64_t sa_k,
                    const float *B, int64_t sb_k, int64_t sb_n,
-                   float *C, int64_t ldc, const float *bias, float *rowsum, int act, int accumulate,
+                   float *C, int64_t ldc, const float *bias, float *rowsum, const float *cmask,
+                   int act, int accumulate,
                    int split_k, void *workspace, size_t workspace_bytes, void *stream);
 
 /* out[n] (+)= sum_m x[m][n] * [mask[m][n] > 0] (mask optional, same ld as x);

@@ -49,6 +49,7 @@ struct GemmArgs {
     long long ldc;
     const float *bias;
     float *rowsum;        // optional [M]: sum_k A(m,k)
+    const float *cmask;   // optional, addressed like C: C(m,n) = 0 where cmask(m,n) <= 0
     int act;
     int accumulate;
     int split_k;
@@ -70,6 +71,7 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs &g, int row, int c
     if (g.act == PSVAE_ACT_RELU) v = fmaxf(v, 0.f);
     float *c = g.C + (long long)row * g.ldc + col;
     if (g.accumulate) v += *c;
+    if (g.cmask && !(g.cmask[(long long)row * g.ldc + col] > 0.f)) v = 0.f;
     *c = v;
 }
 
@@ -316,6 +318,11 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_panel_kernel(GemmArgs g) {
                         const float4 o = *dst;
                         v.x += o.x, v.y += o.y, v.z += o.z, v.w += o.w;
                     }
+                    if (g.cmask) {
+                        const float4 mk = *reinterpret_cast<const float4 *>(g.cmask + (long long)row * ld + col);
+                        v.x = mk.x > 0.f ? v.x : 0.f, v.y = mk.y > 0.f ? v.y : 0.f;
+                        v.z = mk.z > 0.f ? v.z : 0.f, v.w = mk.w > 0.f ? v.w : 0.f;
+                    }
                     *dst = v;
                 }
             }
@@ -550,8 +557,8 @@ extern "C" size_t psvae_gemm_f32_workspace_bytes(int M, int N, int K, int split_
 
 extern "C" int psvae_gemm_f32(int M, int N, int K, const float *A, const float *amask, int64_t sa_m,
                               int64_t sa_k, const float *B, int64_t sb_k, int64_t sb_n, float *C, int64_t ldc,
-                              const float *bias, float *rowsum, int act, int accumulate, int split_k,
-                              void *workspace, size_t workspace_bytes, void *stream) {
+                              const float *bias, float *rowsum, const float *cmask, int act, int accumulate,
+                              int split_k, void *workspace, size_t workspace_bytes, void *stream) {
     PSVAE_REQUIRE(M >= 0 && N >= 0 && K >= 0, PSVAE_EINVAL, "psvae_gemm_f32: negative dimension");
     if (M == 0 || N == 0) return PSVAE_OK;
     PSVAE_REQUIRE(C != nullptr && (K == 0 || (A != nullptr && B != nullptr)), PSVAE_EINVAL,
@@ -571,10 +578,10 @@ extern "C" int psvae_gemm_f32(int M, int N, int K, const float *A, const float *
     g.M = M, g.N = N, g.K = K, g.n_ext = N + (rowsum ? 1 : 0);
     g.ws_ld = (g.n_ext + 3) / 4 * 4;
     g.c_vec = (split_k > 1 ? psvae_aligned16(workspace) : (psvae_aligned16(C) && ldc % 4 == 0)) && N % 4 == 0 &&
-              (bias == nullptr || psvae_aligned16(bias));
+              (bias == nullptr || psvae_aligned16(bias)) && (cmask == nullptr || psvae_aligned16(cmask));
     g.A = A, g.amask = amask, g.sa_m = sa_m, g.sa_k = sa_k;
     g.B = B, g.sb_k = sb_k, g.sb_n = sb_n;
-    g.C = C, g.ldc = ldc, g.bias = bias, g.rowsum = rowsum, g.act = act;
+    g.C = C, g.ldc = ldc, g.bias = bias, g.rowsum = rowsum, g.cmask = cmask, g.act = act;
     g.accumulate = accumulate, g.split_k = split_k, g.k_chunk = k_chunk, g.ws = (float *)workspace;
     const bool a_kc = (sa_k == 1), b_kc = (sb_k == 1);
     hipStream_t s = (hipStream_t)stream;

@@ -34,7 +34,7 @@ _SIGNATURES = {
                                           _c_int, _p, _c_int, _p, _c_int, _p, _c_size, _p]),
     'psvae_gemm_f32_workspace_bytes': (_c_size, [_c_int, _c_int, _c_int, _c_int]),
     'psvae_gemm_f32': (_c_int, [_c_int, _c_int, _c_int, _p, _p, _c_i64, _c_i64, _p, _c_i64, _c_i64, _p, _c_i64,
-                                _p, _p, _c_int, _c_int, _c_int, _p, _c_size, _p]),
+                                _p, _p, _p, _c_int, _c_int, _c_int, _p, _c_size, _p]),
     'psvae_colsum_workspace_bytes': (_c_size, [_c_int, _c_int]),
     'psvae_colsum_f32': (_c_int, [_c_int, _c_int, _p, _p, _c_i64, _p, _c_int, _p, _c_size, _p]),
     'psvae_segment_sum_fwd': (_c_int, [_c_int, _c_int, _p, _c_int, _p, _p, _p, _c_int, _p]),
@@ -204,7 +204,7 @@ def roofline_report(prof, hbm_peak_gbs, mfma_peak_tflops, traffic=None):
 
 # --------------------------------------------------------------------------- raw calls
 def gemm(M, N, K, A, sa_m, sa_k, B, sb_k, sb_n, C, ldc, bias=None, relu=False, accumulate=False,
-         amask=None, split_k=0, rowsum=None):
+         amask=None, split_k=0, rowsum=None, cmask=None):
     L = lib()
     nbytes = L.psvae_gemm_f32_workspace_bytes(M, N, K, split_k)
     ws = workspace(nbytes, C.device) if nbytes else None
@@ -214,7 +214,8 @@ def gemm(M, N, K, A, sa_m, sa_k, B, sb_k, sb_n, C, ldc, bias=None, relu=False, a
     with _Prof('gemm_f32_kernel', 2.0 * M * N * K, tag):
         rc = L.psvae_gemm_f32(M, N, K, ptr(A, torch.float32), ptr(amask, torch.float32), sa_m, sa_k,
                               ptr(B, torch.float32), sb_k, sb_n, ptr(C, torch.float32), ldc,
-                              ptr(bias, torch.float32), ptr(rowsum, torch.float32), 1 if relu else 0,
+                              ptr(bias, torch.float32), ptr(rowsum, torch.float32), ptr(cmask, torch.float32),
+                              1 if relu else 0,
                               1 if accumulate else 0, split_k, ptr(ws), nbytes, _stream())
     _check(rc, 'psvae_gemm_f32')
 

@@ -193,7 +193,7 @@ class _GineEncoder(Function):
     iterate written straight into its slot of the concatenated [V, t*H] output (no cat).
 
     Backward runs the layers in reverse with hand-placed kernels: the ReLU derivative is
-    applied while the gradient operand is loaded, the slot gradient of an iterate is added
+    applied in the epilogue of the product that produces the gradient, the slot gradient of an iterate is added
     inside the aggregation backward, and the gradients of the shared conv weights are ONE
     product each over the t iterations stacked along K (K = t*V) with the bias gradient
     taken from the same pass."""
@@ -233,14 +233,14 @@ class _GineEncoder(Function):
         g_all = g_all if (g_all.dtype == torch.float32 and g_all.is_contiguous()) else g_all.float().contiguous()
         f32 = dict(dtype=torch.float32, device=dev)
         gx = torch.empty(t, V, H, **f32)      # dL/d x_i (output of layer i), stacked for the dW2 product
-        gh = torch.empty(t, V, H, **f32)      # dL/d h_i before the ReLU gate
+        gh = torch.empty(t, V, H, **f32)      # dL/d (pre-activation of h_i): gated as it is produced
         ga = torch.empty(V, H, **f32)
         g_x0 = torch.empty(V, H, **f32)
         g_table = torch.empty_like(table)
         gx[t - 1].copy_(g_all[:, (t - 1) * H:])
         for i in range(t - 1, -1, -1):
-            hip.gemm(V, H, H, gx[i], H, 1, w2, H, 1, gh[i], H)                  # through the last Linear
-            hip.gemm(V, H, H, gh[i], H, 1, w1, H, 1, ga, H, amask=h[i])         # through ReLU + first Linear
+            hip.gemm(V, H, H, gx[i], H, 1, w2, H, 1, gh[i], H, cmask=h[i])      # through the last Linear + ReLU
+            hip.gemm(V, H, H, gh[i], H, 1, w1, H, 1, ga, H)                     # through the first Linear
             first = i == t - 1
             if i > 0:
                 hip.gine_aggregate_bwd(all_x[:, (i - 1) * H:i * H], table, ga, csr.t_row_ptr, csr.t_col, csr.t_cls,
@@ -255,7 +255,7 @@ class _GineEncoder(Function):
         TV = t * V
         gx2, gh2, h2, a2 = gx.view(TV, H), gh.view(TV, H), h.view(TV, H), a.view(TV, H)
         hip.gemm(H, H, TV, gx2, 1, H, h2, H, 1, gw2, H, split_k=0, rowsum=gb2)
-        hip.gemm(H, H, TV, gh2, 1, H, a2, H, 1, gw1, H, amask=h2, split_k=0, rowsum=gb1)
+        hip.gemm(H, H, TV, gh2, 1, H, a2, H, 1, gw1, H, split_k=0, rowsum=gb1)
         gw0, gb0 = torch.empty_like(w0), torch.empty(H, **f32)
         hip.gemm(H, Din, V, g_x0, 1, H, x_in, _ld(x_in), 1, gw0, Din, split_k=0, rowsum=gb0)
         g_in = None

@@ -55,6 +55,12 @@ def test_gemm_forward_shapes(M, N, K):
     gx = torch.empty(M, K, device=d)
     hip.gemm(M, K, N, gy.to(d), N, 1, wd, K, 1, gx, K, amask=act.to(d))
     close(gx, (gy.double() * (act > 0)) @ w.double(), what='dX')
+    # the gate on the result instead: (dY W) * [mask > 0], also through the split-K reduction
+    gate = torch.relu(torch.randn(M, K, generator=g))
+    for split in (1, 3):
+        gx2 = torch.empty(M, K, device=d)
+        hip.gemm(M, K, N, gy.to(d), N, 1, wd, K, 1, gx2, K, cmask=gate.to(d), split_k=split)
+        close(gx2, (gy.double() @ w.double()) * (gate > 0), what=f'gated dX split {split}')
     # weight-gradient form dY^T X, split-K chosen by the library and forced
     for split in (0, 1, 5):
         gw = torch.full((N, K), 3.0, device=d)
