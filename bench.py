@@ -155,12 +155,15 @@ def main():
     # and freeze the survivors so that it cannot land inside the timed region
     gc.collect()
     gc.freeze()
-    hip.PROFILE = {}
+    # kernel events are recorded on every 4th timed step (they cost ~0.6 ms of host time per
+    # step when recorded on all of them)
+    prof = {}
     fence()
     t0 = time.perf_counter()
     stats = {'V': 0, 'E': 0, 'Ein': 0, 'P': 0}
     trace = []
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        hip.PROFILE = prof if i % 4 == 0 else None
         b = step()
         trace.append(time.perf_counter())
         c = b.compact
@@ -173,8 +176,18 @@ def main():
     if os.environ.get('PSVAE_BENCH_TRACE'):
         print('host ms per step (no sync):', [round((b - a) * 1e3, 1) for a, b in zip([t0] + trace[:-1], trace)],
               'final fence ms', round((t0 + elapsed - trace[-1]) * 1e3, 1), file=sys.stderr)
-    prof, hip.PROFILE = hip.PROFILE, None
+    hip.PROFILE = None
     final_loss = float(model.logged['reconstruct loss'].detach())
+    # Outside the timed region: two more steps with the two chains on ONE stream.  In the timed
+    # region kernels of the two streams share the chip, which stretches every bracket; these
+    # brackets time each kernel alone.
+    serial = {}
+    model.two_streams = False
+    hip.PROFILE = serial
+    for _ in range(2):
+        step()
+    fence()
+    hip.PROFILE = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -196,6 +209,12 @@ def main():
             'rec_loss_last_step': round(final_loss, 5),
         }
         out.update(hip.roofline_report(prof, HBM_PEAK_GBS, MFMA_F32_PEAK_TFLOPS, pmc_traffic()))
+        alone = hip.roofline_report(serial, HBM_PEAK_GBS, MFMA_F32_PEAK_TFLOPS, pmc_traffic())
+        out['roofline_one_stream'] = {k: alone[k] for k in ('roofline_mfma', 'roofline_hbm', 'roofline_hbm_bwd')
+                                      if k in alone}
+        out['roofline_note'] = ('roofline*: event brackets on every 4th step of the timed region, where the '
+                                'kernels of two streams run concurrently; roofline_one_stream: the same '
+                                'brackets on 2 extra un-timed steps with everything on one stream')
         if args.gemm_shapes:
             print('M N K A-contig B-contig masked rowsum launches ms TFLOP/s', file=sys.stderr)
             for row in hip.gemm_shape_table(prof):
