@@ -155,15 +155,19 @@ def main():
     # and freeze the survivors so that it cannot land inside the timed region
     gc.collect()
     gc.freeze()
-    # kernel events are recorded on every 4th timed step (they cost ~0.6 ms of host time per
-    # step when recorded on all of them)
-    prof = {}
+    # Kernel events are recorded on a few of the timed steps only (they cost ~0.6 ms of host
+    # time per step).  Steps 0, 16, 32, ... run with everything on ONE stream and fill `prof`:
+    # their brackets time each kernel alone.  Steps 8, 24, ... keep the two streams and fill
+    # `prof_shared`: there kernels of both streams share the chip and every bracket stretches.
+    prof, prof_shared = {}, {}
+    two_streams = model.two_streams
     fence()
     t0 = time.perf_counter()
     stats = {'V': 0, 'E': 0, 'Ein': 0, 'P': 0}
     trace = []
     for i in range(args.steps):
-        hip.PROFILE = prof if i % 4 == 0 else None
+        hip.PROFILE = prof if i % 16 == 0 else (prof_shared if i % 16 == 8 else None)
+        model.two_streams = two_streams and i % 16 != 0
         b = step()
         trace.append(time.perf_counter())
         c = b.compact
@@ -178,16 +182,7 @@ def main():
               'final fence ms', round((t0 + elapsed - trace[-1]) * 1e3, 1), file=sys.stderr)
     hip.PROFILE = None
     final_loss = float(model.logged['reconstruct loss'].detach())
-    # Outside the timed region: two more steps with the two chains on ONE stream.  In the timed
-    # region kernels of the two streams share the chip, which stretches every bracket; these
-    # brackets time each kernel alone.
-    serial = {}
-    model.two_streams = False
-    hip.PROFILE = serial
-    for _ in range(2):
-        step()
-    fence()
-    hip.PROFILE = None
+    model.two_streams = two_streams
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -209,12 +204,13 @@ def main():
             'rec_loss_last_step': round(final_loss, 5),
         }
         out.update(hip.roofline_report(prof, HBM_PEAK_GBS, MFMA_F32_PEAK_TFLOPS, pmc_traffic()))
-        alone = hip.roofline_report(serial, HBM_PEAK_GBS, MFMA_F32_PEAK_TFLOPS, pmc_traffic())
-        out['roofline_one_stream'] = {k: alone[k] for k in ('roofline_mfma', 'roofline_hbm', 'roofline_hbm_bwd')
-                                      if k in alone}
-        out['roofline_note'] = ('roofline*: event brackets on every 4th step of the timed region, where the '
-                                'kernels of two streams run concurrently; roofline_one_stream: the same '
-                                'brackets on 2 extra un-timed steps with everything on one stream')
+        shared = hip.roofline_report(prof_shared, HBM_PEAK_GBS, MFMA_F32_PEAK_TFLOPS, pmc_traffic())
+        out['roofline_two_streams'] = {k: shared[k] for k in ('roofline_mfma', 'roofline_hbm', 'roofline_hbm_bwd')
+                                       if k in shared}
+        out['roofline_note'] = ('roofline*: event brackets on timed steps 0, 16, 32, ..., which run on one '
+                                'stream so that each bracket times its kernel alone; roofline_two_streams: the '
+                                'same brackets on timed steps 8, 24, ..., where kernels of the two streams share '
+                                'the chip; all other timed steps run two streams without events')
         if args.gemm_shapes:
             print('M N K A-contig B-contig masked rowsum launches ms TFLOP/s', file=sys.stderr)
             for row in hip.gemm_shape_table(prof):
