@@ -36,6 +36,9 @@ def parse():
     ap.add_argument('--batch', type=int, default=4096, help='molecules per GPU per step')
     ap.add_argument('--dataset', type=int, default=0, help='synthetic molecules per rank (default 4x batch)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo for rehearsals)')
+    ap.add_argument('--device', type=int, default=-1,
+                    help='GPU index for every rank (rehearsal of N ranks on one GPU); default LOCAL_RANK')
     ap.add_argument('--gemm-shapes', action='store_true', help='per-shape GEMM timing table on stderr')
     ap.add_argument('--cpu-batch', type=int, default=256)
     ap.add_argument('--cpu-steps', type=int, default=3)
@@ -104,15 +107,22 @@ def pmc_traffic():
 
 def main():
     args = parse()
+    if os.environ.get('PSVAE_BENCH_WATCHDOG'):   # dump every thread's stack if the run stalls
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ['PSVAE_BENCH_WATCHDOG']), exit=True)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    dev_index = local_rank if args.device < 0 else args.device
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     if world > 1:
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     import ps_vae_amd  # noqa: F401
     from ps_vae_amd import hip
@@ -184,7 +194,7 @@ def main():
     final_loss = float(model.logged['reconstruct loss'].detach())
     model.two_streams = two_streams
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -38,7 +38,13 @@ class FlatGradSync:
     def sync(self):
         """Average the gradients over the ranks (no-op for a single process)."""
         if self.world > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            if self.flat.is_cuda and dist.get_backend(self.group) == 'gloo':
+                # rehearsals of the multi-rank path without RCCL: stage through host memory
+                host = self.flat.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                self.flat.copy_(host)
+            else:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
             self.flat.div_(self.world)
 
     def clip_grad_norm_(self, max_norm):

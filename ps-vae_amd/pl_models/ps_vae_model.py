@@ -9,6 +9,7 @@ forward() takes either the reference's batch dict (any source) or a CollatedBatc
 the kernels read the CSR / pair lists collation wrote."""
 import os
 import time
+import warnings
 
 import torch
 import torch.nn as nn
@@ -36,6 +37,10 @@ class PSVAEModel(nn.Module):
         self.logged = {}
         # compact path only; PSVAE_STREAMS=1 keeps everything on the current stream
         self.two_streams = os.environ.get('PSVAE_STREAMS', '2') != '1'
+        if self.two_streams:
+            # parameters of the side-stream chain receive their gradients on that stream; autograd
+            # orders the accumulation correctly and says so once per process
+            warnings.filterwarnings('ignore', message="The AccumulateGrad node's stream does not match")
 
     @property
     def device(self):
