@@ -233,6 +233,21 @@ int psvae_pair_gather_bwd(int B, int H, int L, const float *g_feats,
                           float *g_h, int ldgh, float *g_z, int ldgz, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * Two Linear layers with no activation between them as one affine map — the link
+ * predictor's MLP output layer followed by the class layer
+ * (src/modules/vae_piece_decoder.py:42-46, 110):
+ *     w_eff [C,K] = w_last [C,J] . w_out [J,K]      b_eff [C] = w_last . b_out + b_last
+ * Backward returns the gradients of both layers from those of (w_eff, b_eff); the gradient
+ * of b_last is g_b_eff itself.  C <= 8; biases may be NULL (g_b_out NULL with b_out).
+ * ---------------------------------------------------------------------------------- */
+int psvae_affine_merge_fwd(int C, int J, int K, const float *w_last, const float *b_last,
+                           const float *w_out, const float *b_out, float *w_eff, float *b_eff,
+                           void *stream);
+int psvae_affine_merge_bwd(int C, int J, int K, const float *w_last, const float *w_out,
+                           const float *b_out, const float *g_w_eff, const float *g_b_eff,
+                           float *g_w_last, float *g_w_out, float *g_b_out, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * Last Linear of edge_predictor fused with the link loss
  * (src/modules/vae_piece_decoder.py:45,54,110,115): logits = hid W^T + b  [P,C], C <= 8;
  * loss = mean_p( logsumexp(logits[p]) - logits[p][golden[p]] );

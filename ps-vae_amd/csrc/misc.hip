@@ -253,6 +253,94 @@ __global__ void pair_gather_bwd_kernel(int h4, int l4, int slots, const float4 *
     if (zthread) g_z[(long long)b * ldgz4 + threadIdx.x] = zacc;
 }
 
+// ---------------------------------------------------------------- two stacked Linears as one
+// W_eff = W_last W_out, b_eff = W_last b_out + b_last (no activation between the layers).
+// Thread (kq, jg) of a workgroup sums j = jg, jg+8, ... for column k = 32*blockIdx.x + kq and
+// all classes; the 8 partial sums are added in jg order through LDS.  The bias is the virtual
+// column k == K.
+template <int MAXC>
+__global__ __launch_bounds__(256) void affine_merge_fwd_kernel(int C, int J, int K, const float *__restrict__ w_last,
+                                                               const float *__restrict__ b_last,
+                                                               const float *__restrict__ w_out,
+                                                               const float *__restrict__ b_out,
+                                                               float *__restrict__ w_eff, float *__restrict__ b_eff) {
+    __shared__ float sh[8][MAXC][32];
+    const int kq = threadIdx.x & 31, jg = threadIdx.x >> 5;
+    const int k = blockIdx.x * 32 + kq;
+    float acc[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) acc[c] = 0.f;
+    if (k <= K)
+        for (int j = jg; j < J; j += 8) {
+            const float w = k < K ? w_out[(long long)j * K + k] : (b_out ? b_out[j] : 0.f);
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c)
+                if (c < C) acc[c] += w_last[c * J + j] * w;
+        }
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) sh[jg][c][kq] = acc[c];
+    __syncthreads();
+    if (jg == 0 && k <= K) {
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+            if (c < C) {
+                float t = sh[0][c][kq];
+#pragma unroll
+                for (int q = 1; q < 8; ++q) t += sh[q][c][kq];
+                if (k < K)
+                    w_eff[c * K + k] = t;
+                else
+                    b_eff[c] = t + (b_last ? b_last[c] : 0.f);
+            }
+    }
+}
+
+// Backward: one wave per row j of W_out.
+//   g_w_out[j][k] = sum_c w_last[c][j] g_w_eff[c][k]        g_b_out[j] = sum_c w_last[c][j] g_b_eff[c]
+//   g_w_last[c][j] = sum_k g_w_eff[c][k] w_out[j][k] + g_b_eff[c] b_out[j]
+template <int MAXC>
+__global__ __launch_bounds__(256) void affine_merge_bwd_kernel(int C, int J, int K, const float *__restrict__ w_last,
+                                                               const float *__restrict__ w_out,
+                                                               const float *__restrict__ b_out,
+                                                               const float *__restrict__ g_w_eff,
+                                                               const float *__restrict__ g_b_eff,
+                                                               float *__restrict__ g_w_last,
+                                                               float *__restrict__ g_w_out,
+                                                               float *__restrict__ g_b_out) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= J) return;
+    float wl[MAXC], dot[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) wl[c] = c < C ? w_last[c * J + j] : 0.f, dot[c] = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float w = w_out[(long long)j * K + k];
+        float o = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+            if (c < C) {
+                const float ge = g_w_eff[c * K + k];
+                o += wl[c] * ge;
+                dot[c] += ge * w;
+            }
+        g_w_out[(long long)j * K + k] = o;
+    }
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) dot[c] += __shfl_xor(dot[c], d);
+    if (lane == 0) {
+        float gb = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+            if (c < C) {
+                g_w_last[c * J + j] = dot[c] + (b_out ? g_b_eff[c] * b_out[j] : 0.f);
+                gb += wl[c] * g_b_eff[c];
+            }
+        if (g_b_out) g_b_out[j] = gb;
+    }
+}
+
 // ---------------------------------------------------------------- link loss
 // One wave per candidate pair: dot products of the pair's hidden row with the C rows of W
 // (staged in LDS when they fit), then softmax / loss / argmax on lane 0.  VEC: F and ldhid
@@ -574,6 +662,43 @@ extern "C" int psvae_pair_gather_bwd(int B, int H, int L, const float *g_feats, 
                        (const float4 *)g_feats, src, dst, pair_ptr, node_begin, node_end, (float4 *)g_h, ldgh / 4,
                        (float4 *)g_z, ldgz / 4);
     PSVAE_CHECK_LAUNCH("psvae_pair_gather_bwd");
+    return PSVAE_OK;
+}
+
+extern "C" int psvae_affine_merge_fwd(int C, int J, int K, const float *w_last, const float *b_last,
+                                      const float *w_out, const float *b_out, float *w_eff, float *b_eff,
+                                      void *stream) {
+    PSVAE_REQUIRE(C > 0 && J > 0 && K > 0, PSVAE_EINVAL, "psvae_affine_merge_fwd: bad sizes");
+    PSVAE_REQUIRE(C <= 8, PSVAE_ETOOLARGE, "psvae_affine_merge_fwd: at most 8 classes (C=%d)", C);
+    PSVAE_REQUIRE(w_last && w_out && w_eff && b_eff, PSVAE_EINVAL, "psvae_affine_merge_fwd: null pointer");
+    const dim3 grid(psvae_cdiv(K + 1, 32));
+    if (C <= 4)
+        hipLaunchKernelGGL(affine_merge_fwd_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, C, J, K, w_last, b_last,
+                           w_out, b_out, w_eff, b_eff);
+    else
+        hipLaunchKernelGGL(affine_merge_fwd_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, C, J, K, w_last, b_last,
+                           w_out, b_out, w_eff, b_eff);
+    PSVAE_CHECK_LAUNCH("psvae_affine_merge_fwd");
+    return PSVAE_OK;
+}
+
+extern "C" int psvae_affine_merge_bwd(int C, int J, int K, const float *w_last, const float *w_out,
+                                      const float *b_out, const float *g_w_eff, const float *g_b_eff,
+                                      float *g_w_last, float *g_w_out, float *g_b_out, void *stream) {
+    PSVAE_REQUIRE(C > 0 && J > 0 && K > 0, PSVAE_EINVAL, "psvae_affine_merge_bwd: bad sizes");
+    PSVAE_REQUIRE(C <= 8, PSVAE_ETOOLARGE, "psvae_affine_merge_bwd: at most 8 classes (C=%d)", C);
+    PSVAE_REQUIRE(w_last && w_out && g_w_eff && g_b_eff && g_w_last && g_w_out, PSVAE_EINVAL,
+                  "psvae_affine_merge_bwd: null pointer");
+    PSVAE_REQUIRE((b_out == nullptr) == (g_b_out == nullptr), PSVAE_EINVAL,
+                  "psvae_affine_merge_bwd: b_out and g_b_out go together");
+    const dim3 grid(psvae_cdiv(J, 4));
+    if (C <= 4)
+        hipLaunchKernelGGL(affine_merge_bwd_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, C, J, K, w_last, w_out,
+                           b_out, g_w_eff, g_b_eff, g_w_last, g_w_out, g_b_out);
+    else
+        hipLaunchKernelGGL(affine_merge_bwd_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, C, J, K, w_last, w_out,
+                           b_out, g_w_eff, g_b_eff, g_w_last, g_w_out, g_b_out);
+    PSVAE_CHECK_LAUNCH("psvae_affine_merge_bwd");
     return PSVAE_OK;
 }
 

@@ -7,8 +7,9 @@ trainer (src/guacamol_exps/goal_directed/train.py:159-161, 268-276).  Semantics 
 standard DDP: every rank computes the gradient of its own batch's loss (means over the
 rank-local pair / token / molecule counts) and the ranks' gradients are averaged.
 
-All parameter gradients are views into one contiguous buffer, so the exchange is a single
-collective of 7.57 MB (1 891 727 fp32) with no bucketing, packing or unpacking kernels.
+After backward the gradients are packed into one contiguous buffer by a single multi-tensor
+copy and every .grad becomes a view of it, so the exchange is a single collective of 7.57 MB
+(1 891 727 fp32) and clipping / the optimiser work on the same memory.
 Parameters that never receive a gradient (decoder.graph_embedding.linear.*, 1 201 elements)
 simply stay zero in the buffer and are never waited on."""
 import torch
@@ -24,19 +25,39 @@ class FlatGradSync:
         total = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(total, dtype=dtype, device=dev)
         off = 0
+        self.views = []
         for p in self.params:
             n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)
+            self.views.append(self.flat[off:off + n].view_as(p))
+            p.grad = self.views[-1]
             off += n
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
 
     def zero_grad(self):
-        """Instead of optimizer.zero_grad(set_to_none=True), which would detach the views."""
-        self.flat.zero_()
+        """Drop the gradients: backward then hands every parameter its gradient tensor as
+        produced (no per-parameter accumulation kernels) and sync() packs them."""
+        for p in self.params:
+            p.grad = None
+
+    def pack(self):
+        """Copy the gradients backward produced into the flat buffer (one multi-tensor copy) and
+        point every .grad at its slice; parameters without a gradient get zeros."""
+        src, dst = [], []
+        for p, v in zip(self.params, self.views):
+            g = p.grad
+            if g is None:
+                v.zero_()
+            elif g.data_ptr() != v.data_ptr():
+                src.append(g)
+                dst.append(v)
+            p.grad = v
+        if src:
+            torch._foreach_copy_(dst, src)
 
     def sync(self):
-        """Average the gradients over the ranks (no-op for a single process)."""
+        """Pack, then average the gradients over the ranks (one process: pack only)."""
+        self.pack()
         if self.world > 1:
             if self.flat.is_cuda and dist.get_backend(self.group) == 'gloo':
                 # rehearsals of the multi-rank path without RCCL: stage through host memory

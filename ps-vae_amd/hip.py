@@ -35,6 +35,8 @@ _SIGNATURES = {
     'psvae_gemm_f32_workspace_bytes': (_c_size, [_c_int, _c_int, _c_int, _c_int]),
     'psvae_gemm_f32': (_c_int, [_c_int, _c_int, _c_int, _p, _p, _c_i64, _c_i64, _p, _c_i64, _c_i64, _p, _c_i64,
                                 _p, _p, _p, _c_int, _c_int, _c_int, _p, _c_size, _p]),
+    'psvae_affine_merge_fwd': (_c_int, [_c_int, _c_int, _c_int, _p, _p, _p, _p, _p, _p, _p]),
+    'psvae_affine_merge_bwd': (_c_int, [_c_int, _c_int, _c_int, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     'psvae_colsum_workspace_bytes': (_c_size, [_c_int, _c_int]),
     'psvae_colsum_f32': (_c_int, [_c_int, _c_int, _p, _p, _c_i64, _p, _c_int, _p, _c_size, _p]),
     'psvae_segment_sum_fwd': (_c_int, [_c_int, _c_int, _p, _c_int, _p, _p, _p, _c_int, _p]),
@@ -218,6 +220,25 @@ def gemm(M, N, K, A, sa_m, sa_k, B, sb_k, sb_n, C, ldc, bias=None, relu=False, a
                               1 if relu else 0,
                               1 if accumulate else 0, split_k, ptr(ws), nbytes, _stream())
     _check(rc, 'psvae_gemm_f32')
+
+
+def affine_merge_fwd(w_last, b_last, w_out, b_out, w_eff, b_eff):
+    C, J = w_last.shape
+    K = w_out.shape[1]
+    _check(lib().psvae_affine_merge_fwd(C, J, K, ptr(w_last, torch.float32), ptr(b_last, torch.float32),
+                                        ptr(w_out, torch.float32), ptr(b_out, torch.float32),
+                                        ptr(w_eff, torch.float32), ptr(b_eff, torch.float32), _stream()),
+           'psvae_affine_merge_fwd')
+
+
+def affine_merge_bwd(w_last, w_out, b_out, g_w_eff, g_b_eff, g_w_last, g_w_out, g_b_out):
+    C, J = w_last.shape
+    K = w_out.shape[1]
+    _check(lib().psvae_affine_merge_bwd(C, J, K, ptr(w_last, torch.float32), ptr(w_out, torch.float32),
+                                        ptr(b_out, torch.float32), ptr(g_w_eff, torch.float32),
+                                        ptr(g_b_eff, torch.float32), ptr(g_w_last, torch.float32),
+                                        ptr(g_w_out, torch.float32), ptr(g_b_out, torch.float32), _stream()),
+           'psvae_affine_merge_bwd')
 
 
 def colsum(x, out, mask=None, accumulate=False):

@@ -79,12 +79,11 @@ class VAEPieceDecoder(nn.Module):
         if isinstance(seq, nn.Sequential) and len(seq) > 1 and isinstance(seq[-1], nn.Linear):
             # No activation sits between the MLP's output layer and the class layer, so the
             # two are one affine map: W = W_last W_out, b = W_last b_out + b_last.  The wide
-            # intermediate [P, mlp_in] is never formed; autograd carries the gradient of
-            # (W, b) back to both layers through the two small products.
+            # intermediate [P, mlp_in] is never formed; the gradient of (W, b) goes back to both
+            # layers through one small kernel.
             inner = seq[-1]
             hid = run_sequential(seq[:-1], feats)
-            weight = ops.linear(last.weight, inner.weight.t())
-            bias = ops.linear(inner.bias.unsqueeze(0), last.weight, last.bias).squeeze(0)
+            weight, bias = ops.affine_merge(last.weight, last.bias, inner.weight, inner.bias)
         else:
             hid = mlp(feats)
             weight, bias = last.weight, last.bias

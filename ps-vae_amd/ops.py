@@ -445,6 +445,36 @@ def pair_gather(h, z, pairs):
     return _PairGather.apply(h, z, pairs)
 
 
+# ------------------------------------------------------------------------ two Linears as one
+class _AffineMerge(Function):
+    @staticmethod
+    def forward(ctx, w_last, b_last, w_out, b_out):
+        w_last, w_out = w_last.contiguous(), w_out.contiguous()
+        C, K = w_last.shape[0], w_out.shape[1]
+        w_eff = torch.empty(C, K, dtype=torch.float32, device=w_last.device)
+        b_eff = torch.empty(C, dtype=torch.float32, device=w_last.device)
+        hip.affine_merge_fwd(w_last, b_last, w_out, b_out, w_eff, b_eff)
+        ctx.save_for_backward(w_last, w_out, b_out)
+        ctx.has_b_last = b_last is not None
+        return w_eff, b_eff
+
+    @staticmethod
+    def backward(ctx, g_w_eff, g_b_eff):
+        w_last, w_out, b_out = ctx.saved_tensors
+        g_w_eff = g_w_eff.contiguous().float()
+        g_b_eff = (torch.zeros(w_last.shape[0], dtype=torch.float32, device=w_last.device) if g_b_eff is None
+                   else g_b_eff.contiguous().float())
+        g_w_last, g_w_out = torch.empty_like(w_last), torch.empty_like(w_out)
+        g_b_out = torch.empty_like(b_out) if b_out is not None else None
+        hip.affine_merge_bwd(w_last, w_out, b_out, g_w_eff, g_b_eff, g_w_last, g_w_out, g_b_out)
+        return g_w_last, (g_b_eff if ctx.has_b_last else None), g_w_out, g_b_out
+
+
+def affine_merge(w_last, b_last, w_out, b_out):
+    """(W, b) of x -> W_last (W_out x + b_out) + b_last: W = W_last W_out, b = W_last b_out + b_last."""
+    return _AffineMerge.apply(w_last, b_last, w_out, b_out)
+
+
 # ------------------------------------------------------------------------ link loss
 class _LinkCe(Function):
     @staticmethod

@@ -245,6 +245,32 @@ def test_rsample_kl_fwd_bwd():
     close(pd.grad, pre.grad, what='d/dlogvar')
 
 
+@pytest.mark.parametrize('C,J,K,bias', [(4, 656, 328, True), (3, 70, 33, True), (8, 40, 100, False)])
+def test_affine_merge(C, J, K, bias):
+    """W_last (W_out x + b_out) + b_last as one affine map, and the gradients of both layers."""
+    from ps_vae_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(C * 100 + J)
+    wl = torch.randn(C, J, generator=g, dtype=torch.float64, requires_grad=True)
+    wo = torch.randn(J, K, generator=g, dtype=torch.float64, requires_grad=True)
+    bl = torch.randn(C, generator=g, dtype=torch.float64, requires_grad=True) if bias else None
+    bo = torch.randn(J, generator=g, dtype=torch.float64, requires_grad=True) if bias else None
+    gw = torch.randn(C, K, generator=g, dtype=torch.float64)
+    gb = torch.randn(C, generator=g, dtype=torch.float64)
+    w_ref = wl @ wo
+    b_ref = (wl @ bo + bl) if bias else torch.zeros(C, dtype=torch.float64)
+    ((w_ref * gw).sum() + ((b_ref * gb).sum() if bias else 0.0)).backward()
+
+    leaves = [t.detach().float().to(d).requires_grad_(True) if t is not None else None for t in (wl, bl, wo, bo)]
+    w_eff, b_eff = ops.affine_merge(*leaves)
+    close(w_eff, w_ref, what='W_eff')
+    close(b_eff, b_ref, what='b_eff')
+    ((w_eff * gw.float().to(d)).sum() + (b_eff * gb.float().to(d)).sum()).backward()
+    for got, want, name in zip(leaves, (wl, bl, wo, bo), ('W_last', 'b_last', 'W_out', 'b_out')):
+        if want is not None:
+            close(got.grad, want.grad, what=f'grad {name}')
+
+
 @pytest.mark.parametrize('T,B', [(1, 3), (7, 300), (9, 33)])
 def test_gru_fwd_bwd(T, B):
     from ps_vae_amd import ops
