@@ -178,7 +178,7 @@ struct TileLoader {
 // WN = 1: the 4 waves stack along M (128-row panel, 32*TN columns).  WN = 2: a 2 x 2 wave grid
 // (64 rows x 64*TN columns), for products whose M fits 64-row panels with less padding.
 template <int TN, int BK, bool A_KC, bool B_KC, bool MASK, bool ONES, int WN = 1>
-__global__ __launch_bounds__(THREADS, 2) void gemm_panel_kernel(GemmArgs g) {
+__global__ __launch_bounds__(THREADS, (MASK || WN > 1 || TN > 5) ? 2 : 3) void gemm_panel_kernel(GemmArgs g) {
     constexpr int WM = 4 / WN, BM = 32 * WM, BN = 32 * TN * WN;
     using LA = TileLoader<BM, BK, A_KC>;
     using LB = TileLoader<BN, BK, B_KC>;
