@@ -202,6 +202,8 @@ __global__ __launch_bounds__(THREADS, (MASK || WN > 1 || TN > 5) ? 2 : 3) void g
     const int l31 = lane & 31, lhi = lane >> 5;
     const int ones_x = g.N;
     const int n_lim = min(g.N, n0 + g.bn);   // columns of B this tile may read
+    // accumulator tiles of this wave that hold at least one real column (wave-uniform)
+    const int tn_live = (min(g.n_ext, n0 + g.bn) - n0 - wave_n * TN * 32 + 31) >> 5;
 
     f32x16 acc[TN];
 #pragma unroll
@@ -258,7 +260,10 @@ __global__ __launch_bounds__(THREADS, (MASK || WN > 1 || TN > 5) ? 2 : 3) void g
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur[j], acc[j], 0, 0, 0);
+                // the last column tile of a wide product may leave up to two tiles empty (N = 328 as
+                // 2 x 192, 600 as 3 x 224); tiles of 5 or fewer never do for this model's widths
+                if (TN < 6 || j + 2 < TN || j < tn_live)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur[j], acc[j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (kk + 2 < BK) {
                 a_cur = a_nxt;
