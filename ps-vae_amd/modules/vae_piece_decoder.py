@@ -186,6 +186,64 @@ class VAEPieceDecoder(nn.Module):
         order = kept[torch.argsort(conf[kept], descending=True, stable=True)]
         return idx, conf, etype.to(torch.int64), order.tolist()
 
+    @torch.no_grad()
+    def infer_links_batch(self, z, x, x_pieces, x_pos, node_off, csr_in, frag, add_edge_th):
+        """infer_links for many generated molecules at once (the link-prediction slice of
+        :203-241 over a batch; the reference loops over molecules in Python,
+        src/pl_models/ps_vae_model.py:139-141).
+
+        z [B,L]; x / x_pieces / x_pos / frag: flat [V] per-atom ids of all molecules
+        (molecule b owns atoms node_off[b] .. node_off[b+1]); csr_in: ops.Csr of the in-piece
+        bonds over the flat node ids; frag: fragment id of every atom (any integers, distinct
+        per fragment inside a molecule).  Candidates of a molecule are its atom pairs (m < n)
+        in different fragments, in row-major order.
+
+        Returns a dict: graph / m / n [Ec] (molecule and molecule-local atom ids of every
+        candidate), conf, etype [Ec], ptr [B+1] (candidates of molecule b are ptr[b]..ptr[b+1]),
+        order [Ek] (indices of the kept candidates: conf >= add_edge_th and type != None,
+        grouped by molecule, confidence descending, stable) and order_ptr [B+1]."""
+        dev = self.W_mean.weight.device
+        node_off = node_off.to(dev).to(torch.int64)
+        B = node_off.numel() - 1
+        n = node_off[1:] - node_off[:-1]
+        cell_off = torch.zeros(B + 1, dtype=torch.int64, device=dev)
+        cell_off[1:] = torch.cumsum(n * n, 0)
+        total = int(cell_off[-1].item())
+        graph = torch.repeat_interleave(torch.arange(B, device=dev), n * n, output_size=total)
+        local = torch.arange(total, device=dev) - cell_off[graph]
+        ng = n[graph]
+        m, k = local // ng.clamp(min=1), local % ng.clamp(min=1)
+        frag = frag.to(dev).to(torch.int64)
+        src, dst = node_off[graph] + m, node_off[graph] + k
+        sel = (m < k) & (frag[src] != frag[dst])
+        graph, m, k, src, dst = graph[sel], m[sel], k[sel], src[sel], dst[sel]
+        ptr = torch.zeros(B + 1, dtype=torch.int32, device=dev)
+        ptr[1:] = torch.cumsum(torch.bincount(graph, minlength=B), 0)
+        no32 = node_off.to(torch.int32)
+        pairs = ops.PairList(src.to(torch.int32), dst.to(torch.int32), graph.to(torch.int32), ptr,
+                             ops.Segments.from_offsets(no32))
+        out = {'graph': graph, 'm': m, 'n': k, 'ptr': ptr}
+        P = src.numel()
+        if P == 0:
+            out.update(conf=torch.zeros(0, device=dev), etype=torch.zeros(0, dtype=torch.int64, device=dev),
+                       order=torch.zeros(0, dtype=torch.int64, device=dev),
+                       order_ptr=torch.zeros(B + 1, dtype=torch.int64, device=dev))
+            return out
+        node_x = self.embed_atom(x.to(dev), x_pieces.to(dev), x_pos.to(dev))
+        h, _ = self.graph_embedding.embed_node(node_x, csr_in, None)
+        logits, _, _ = self.link_logits(h, z.to(dev).view(B, -1), pairs)
+        conf = torch.empty(P, dtype=torch.float32, device=dev)
+        etype = torch.empty(P, dtype=torch.int32, device=dev)
+        keep = torch.empty(P, dtype=torch.uint8, device=dev)
+        hip.link_infer(logits.contiguous(), add_edge_th, self.tokenizer.chem_vocab.bond_to_idx(None), conf, etype, keep)
+        kept = keep.bool().nonzero().flatten()
+        by_conf = kept[torch.argsort(conf[kept], descending=True, stable=True)]
+        order = by_conf[torch.argsort(graph[by_conf], stable=True)]
+        order_ptr = torch.zeros(B + 1, dtype=torch.int64, device=dev)
+        order_ptr[1:] = torch.cumsum(torch.bincount(graph[order], minlength=B), 0)
+        out.update(conf=conf, etype=etype.to(torch.int64), order=order, order_ptr=order_ptr)
+        return out
+
     def inference(self, z, max_atom_num, add_edge_th, temperature):
         raise NotImplementedError(
             'molecule assembly needs RDKit (piece SMILES -> atoms, valence / cycle checks, sanitisation: '

@@ -239,6 +239,79 @@ def test_infer_links_against_reference_golden(tokenizer):
             assert sorted(order) == sorted(want) or not safe
 
 
+def test_infer_links_batch_equals_per_molecule(tokenizer):
+    """The batched link prediction returns, molecule by molecule, what infer_links returns for
+    that molecule alone (which the reference golden pins), on the golden cases run as ONE batch
+    and on 64 synthetic molecules."""
+    from ps_vae_amd import ops as hops
+    from ps_vae_amd.data.synthetic import synthetic_step1
+    gold = load_npz('infer_links.npz')
+    state = {k: torch.from_numpy(v) for k, v in sub(gold, 'state').items()}
+    model, _ = hip_model(tokenizer, state=state, **SMALL)
+    dec = model.decoder
+    th = float(gold['add_edge_th'])
+    mols = []
+    for c in range(int(gold['num_cases'])):
+        g = sub(gold, f'case{c}')
+        groups, p = [], 0
+        for ln in g['groups_len']:
+            groups.append(g['groups_flat'][p:p + ln].tolist())
+            p += ln
+        mols.append(dict(z=torch.from_numpy(g['z']).reshape(-1), x=torch.from_numpy(g['x']).reshape(-1),
+                         xp=torch.from_numpy(g['x_pieces']).reshape(-1), xq=torch.from_numpy(g['x_pos']).reshape(-1),
+                         ei=torch.from_numpy(g['edge_index']), ea=torch.from_numpy(g['edge_attr']), groups=groups))
+    rng = np.random.default_rng(5)
+    latent = mols[0]['z'].numel()
+    for d in synthetic_step1(64, seed=11, shape='zinc'):
+        n = len(d['x'])
+        frag = np.zeros(n, dtype=np.int64)
+        for gi, grp in enumerate(d['groups']):
+            frag[grp] = gi
+        bonds = [(a, b, c) for (a, b), c in zip(d['edge_index'], d['edge_attr']) if frag[a] == frag[b]]
+        ei = torch.tensor([[a for a, b, c in bonds] + [b for a, b, c in bonds],
+                           [b for a, b, c in bonds] + [a for a, b, c in bonds]], dtype=torch.int64).reshape(2, -1)
+        cls = torch.tensor([c for a, b, c in bonds] * 2, dtype=torch.int64)
+        ea = torch.nn.functional.one_hot(cls, 4).to(torch.int64) if len(bonds) else torch.zeros(0, 4, dtype=torch.int64)
+        pieces = np.asarray(d['pieces'])
+        mols.append(dict(z=torch.from_numpy(rng.standard_normal(latent).astype(np.float32)),
+                         x=torch.tensor(d['x']), xp=torch.from_numpy(pieces[frag]), xq=torch.from_numpy(frag),
+                         ei=ei, ea=ea, groups=[g for g in d['groups'] if len(g)]))
+    # one flat batch
+    node_off = np.concatenate([[0], np.cumsum([m['x'].numel() for m in mols])])
+    cat = lambda key: torch.cat([m[key] for m in mols])
+    frag_all = []
+    for mol in mols:
+        f = torch.full((mol['x'].numel(),), -1, dtype=torch.int64)
+        for gi, grp in enumerate(mol['groups']):
+            f[torch.as_tensor(grp, dtype=torch.int64)] = gi
+        assert (f >= 0).all()
+        frag_all.append(f)
+    ei_all = torch.cat([m['ei'] + int(o) for m, o in zip(mols, node_off[:-1])], dim=1)
+    ea_all = torch.cat([m['ea'] for m in mols])
+    V = int(node_off[-1])
+    csr = hops.Csr.from_edge_index(ei_all.to(dev()), ea_all.to(dev()), V)
+    res = dec.infer_links_batch(torch.stack([m['z'] for m in mols]), cat('x'), cat('xp'), cat('xq'),
+                                torch.from_numpy(node_off), csr, torch.cat(frag_all), th)
+    ptr, optr = res['ptr'].cpu().numpy(), res['order_ptr'].cpu().numpy()
+    for b, mol in enumerate(mols):
+        pairs, conf, etype, order = dec.infer_links(mol['z'], mol['x'], mol['xp'], mol['xq'], mol['ei'], mol['ea'],
+                                                    mol['groups'], th)
+        lo, hi = ptr[b], ptr[b + 1]
+        assert hi - lo == pairs.shape[0]
+        assert np.array_equal(torch.stack([res['m'][lo:hi], res['n'][lo:hi]], 1).cpu().numpy(), pairs.cpu().numpy())
+        close(res['conf'][lo:hi], conf, rel=2e-5, what=f'molecule {b} confidence')
+        assert np.array_equal(res['etype'][lo:hi].cpu().numpy(), etype.cpu().numpy())
+        got = (res['order'][optr[b]:optr[b + 1]] - int(lo)).cpu().tolist()
+        c = conf.cpu().numpy()
+        safe = all(abs(v - th) > 1e-5 for v in c)
+        srt = np.sort(c[order])[::-1] if len(order) else np.zeros(0)
+        distinct = len(order) < 2 or float(np.min(-np.diff(srt))) > 1e-6
+        if safe and distinct:
+            assert got == order
+        elif safe:
+            assert sorted(got) == sorted(order)
+
+
 def test_process_step3_same_seed_as_reference(tokenizer):
     """BPEMolDataset.process_step3 draws random.random() in the reference's order: under the
     seed the golden batch was made with it must return that batch."""
