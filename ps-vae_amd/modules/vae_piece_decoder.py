@@ -187,6 +187,70 @@ class VAEPieceDecoder(nn.Module):
         return idx, conf, etype.to(torch.int64), order.tolist()
 
     @torch.no_grad()
+    def sample_pieces_batch(self, z, max_atom_num, temperature, uniforms=None, piece_atom_counts=None,
+                            generator=None):
+        """The piece sampling loop of `inference` (:134-158) for a batch of latents: every step
+        is one GRU cell over all still-active molecules (two GEMMs + the fused gate kernel),
+        the vocabulary projection, the pad / first-step end masks, softmax(logits / T) and one
+        draw per molecule.  The draw is the inverse-CDF form of torch.multinomial(probs, 1):
+        piece = first index whose cumulative probability reaches uniforms[b, t] (uniforms
+        [B, max_pos] in [0,1), drawn here when None).  A molecule stops after the end token,
+        when its atom count exceeds max_atom_num or at max_pos pieces, and its last sampled
+        piece is dropped (:154-158).  Returns (piece_ids [B, max_pos-ish] padded with pad_idx,
+        lengths [B])."""
+        dev = self.W_mean.weight.device
+        tok = self.tokenizer
+        z = z.to(dev).float().reshape(-1, self.latent_dim)
+        B = z.shape[0]
+        max_pos = self.pos_embedding.num_embeddings
+        pad, end = tok.pad_idx(), tok.end_idx()
+        if piece_atom_counts is None:
+            piece_atom_counts = tok.piece_atom_counts()
+        cnt = torch.as_tensor(piece_atom_counts, dtype=torch.int64, device=dev)
+        if uniforms is None:
+            uniforms = torch.rand(B, max_pos, device=dev, generator=generator)
+        uniforms = uniforms.to(dev).float()
+        rnn = self.rnn
+        H = rnn.hidden_size
+        w_ih, w_hh = rnn.weight_ih_l0.contiguous(), rnn.weight_hh_l0.contiguous()
+        E = w_ih.shape[1]
+        h = run_linear(self.latent_to_rnn_hidden, z).contiguous()
+        h_next = torch.empty_like(h)
+        gi = torch.empty(B, 3 * H, device=dev)
+        gh = torch.empty(B, 3 * H, device=dev)
+        gates = torch.empty(B, 3 * H, device=dev)
+        cur = torch.full((B,), end, dtype=torch.int64, device=dev)
+        out = torch.full((B, max_pos), pad, dtype=torch.int64, device=dev)
+        length = torch.zeros(B, dtype=torch.int64, device=dev)
+        atoms = torch.zeros(B, dtype=torch.int64, device=dev)
+        active = torch.ones(B, dtype=torch.bool, device=dev)
+        V = tok.num_piece_type()
+        for t in range(max_pos):
+            emb = self.piece_embedding(cur).contiguous()
+            hip.gemm(B, 3 * H, E, emb, E, 1, w_ih, 1, E, gi, 3 * H, bias=rnn.bias_ih_l0)
+            hip.gemm(B, 3 * H, H, h, H, 1, w_hh, 1, H, gh, 3 * H, bias=rnn.bias_hh_l0)
+            hip.gru_cell_fwd(gi, gh, h, h_next, gates)
+            logits = run_linear(self.to_vocab, h_next)
+            logits[:, pad] = float('-inf')
+            if t == 0:
+                logits[:, end] = float('-inf')
+            probs = torch.softmax(logits / temperature, dim=-1)
+            idx = (torch.cumsum(probs, dim=-1) < uniforms[:, t:t + 1]).sum(dim=-1).clamp(max=V - 1)
+            idx = torch.where(active, idx, torch.full_like(idx, pad))
+            out[:, t] = idx
+            length += active
+            atoms += torch.where(active, cnt[idx], torch.zeros_like(atoms))
+            stop = (idx == end) | (atoms > max_atom_num) | (length == max_pos)
+            active &= ~stop
+            h, h_next = h_next, h
+            cur = torch.where(active, idx, torch.full_like(idx, end))
+            if t % 8 == 7 and not bool(active.any()):
+                break
+        lengths = (length - 1).clamp(min=0)
+        keep = torch.arange(max_pos, device=dev)[None, :] < lengths[:, None]
+        return torch.where(keep, out, torch.full_like(out, pad)), lengths
+
+    @torch.no_grad()
     def infer_links_batch(self, z, x, x_pieces, x_pos, node_off, csr_in, frag, add_edge_th):
         """infer_links for many generated molecules at once (the link-prediction slice of
         :203-241 over a batch; the reference loops over molecules in Python,

@@ -40,3 +40,9 @@ class GeneralVocab:
 
     def num_bond_type(self):
         return len(self.idx2bond)
+
+
+def cnt_atom(smi):
+    """Characters of a (kekulised) piece SMILES that are keys of MAX_VALENCE
+    (src/utils/chem_utils.py:158-163): the atom count the sampling loop budgets with."""
+    return sum(1 for c in smi if c in MAX_VALENCE)

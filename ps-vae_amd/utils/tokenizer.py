@@ -1,7 +1,7 @@
 """Vocabulary-file Tokenizer surface needed by the hot path (src/data/mol_bpe.py:156-249):
 special-token layout and id lookups.  Tokenising a molecule (the greedy principal-subgraph
 merge, :175-222) needs RDKit canonical SMILES and is outside the path."""
-from .chem_vocab import GeneralVocab
+from .chem_vocab import GeneralVocab, cnt_atom
 
 
 class Tokenizer:
@@ -38,6 +38,10 @@ class Tokenizer:
 
     def piece_to_idx(self, piece):
         return self.piece2idx[piece]
+
+    def piece_atom_counts(self):
+        """cnt_atom(idx_to_piece(id)) for every piece id (src/modules/vae_piece_decoder.py:152)."""
+        return [cnt_atom(smi) for smi in self.idx2piece]
 
     def pad_idx(self):
         return self.piece2idx[self.pad]

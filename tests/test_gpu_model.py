@@ -239,6 +239,30 @@ def test_infer_links_against_reference_golden(tokenizer):
             assert sorted(order) == sorted(want) or not safe
 
 
+def test_sample_pieces_batch_against_oracle(tokenizer):
+    """Batched piece sampling = the oracle's per-latent loop on the same uniforms (ids exact).
+    No reference fixture covers sampling (torch.multinomial's own stream): parity unpinned."""
+    model, cfg = hip_model(tokenizer, seed=77, **SMALL)
+    ref = model_ref.PSVAEModel(cfg, tokenizer)
+    ref.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()}, strict=True)
+    B, max_pos = 48, model.decoder.pos_embedding.num_embeddings
+    g = torch.Generator().manual_seed(3)
+    z = torch.randn(B, SMALL['latent_dim'], generator=g) * 2.0
+    u = torch.rand(B, max_pos, generator=g)
+    counts = (torch.arange(tokenizer.num_piece_type()) % 6 + 1).tolist()
+    counts[tokenizer.end_idx()] = 0
+    counts[tokenizer.pad_idx()] = 0
+    for max_atoms, temp in ((20, 1.0), (60, 0.7), (10 ** 6, 1.3)):
+        ids, lengths = model.decoder.sample_pieces_batch(z, max_atoms, temp, uniforms=u, piece_atom_counts=counts)
+        ids, lengths = ids.cpu(), lengths.cpu()
+        with torch.no_grad():
+            for b in range(B):
+                want = ref.decoder.sample_pieces(z[b], max_atoms, temp, u[b], counts)
+                assert lengths[b].item() == len(want), (b, lengths[b].item(), len(want))
+                assert ids[b, :len(want)].tolist() == want
+                assert (ids[b, len(want):] == tokenizer.pad_idx()).all()
+
+
 def test_infer_links_batch_equals_per_molecule(tokenizer):
     """The batched link prediction returns, molecule by molecule, what infer_links returns for
     that molecule alone (which the reference golden pins), on the golden cases run as ONE batch

@@ -123,3 +123,18 @@ def test_tokenizer_vocab_file(tmp_path):
     assert tok.piece_to_idx('CC') == 1 and tok.idx_to_piece(2) == 'c1ccccc1'
     assert tok.num_atom_type() == 11 and tok.atom_pad_idx() == 10
     assert tok.chem_vocab.bond_to_idx(None) == 0 and tok.chem_vocab.num_bond_type() == 4
+
+
+def test_cnt_atom_and_piece_atom_counts(tmp_path):
+    """cnt_atom counts the single characters that are MAX_VALENCE keys
+    (src/utils/chem_utils.py:158-163); the tokenizer exposes it per piece id."""
+    from ps_vae_amd.utils.chem_vocab import cnt_atom
+    from ps_vae_amd.utils.tokenizer import Tokenizer
+    assert cnt_atom('C1=CC=CC=C1') == 6
+    assert cnt_atom('CCl') == 2 and cnt_atom('BrC') == 2 and cnt_atom('<s>') == 0 and cnt_atom('C[NH3+]') == 2
+    vocab = tmp_path / 'vocab.txt'
+    vocab.write_text('C\t1\t10\nCC\t2\t5\nC1CC1\t3\t2\n')
+    tok = Tokenizer(str(vocab))
+    counts = tok.piece_atom_counts()
+    assert counts[:3] == [1, 2, 3] and counts[tok.pad_idx()] == 0 and counts[tok.end_idx()] == 0
+
