@@ -272,6 +272,28 @@ int psvae_link_ce_bwd_input(int P, int F, int C, const float *dlogits, const flo
 int psvae_link_infer(int P, int C, const float *logits, float add_edge_th, int none_bond,
                      float *conf, int32_t *etype, uint8_t *keep, void *stream);
 
+/* ------------------------------------------------------------------------------------
+ * Greedy bond assembly of B generated molecules (src/modules/vae_piece_decoder.py:245-270 with
+ * valence_check / cycle_check of src/utils/chem_utils.py:447-483), one lane per molecule.
+ * Flat per-atom arrays [V] (molecule b owns node_off[b] .. node_off[b+1]): atom_type (chemical
+ * vocabulary index), block0 (fragment index of the atom inside its molecule, 0 .. n_blocks[b]-1).
+ * row_ptr/col/cls: existing (in-fragment) bonds as a symmetric CSR over the flat atom ids, cls =
+ * bond order 1..3.  Candidates of molecule b are entries order_ptr[b] .. order_ptr[b+1] of
+ * ord_m / ord_n (molecule-local atom ids) and ord_type (bond class), already in visiting order.
+ * max_valence[n_atom_type]; sulfur_idx = index of 'S' (the 2-or-6 rule, :479-481).
+ * Out: accepted[k] (bond k was added), block[V] (final connected block of every atom),
+ * keep_atom[V] (atom belongs to the largest block), status[B] (0 ok, 1 degree overflow,
+ * 2 bad ids).
+ * ---------------------------------------------------------------------------------- */
+size_t psvae_assemble_links_workspace_bytes(int V);
+int psvae_assemble_links(int B, int V, const int32_t *node_off, const int32_t *atom_type,
+                         const int32_t *block0, const int32_t *n_blocks,
+                         const int32_t *row_ptr, const int32_t *col, const uint8_t *cls,
+                         const int32_t *order_ptr, const int32_t *ord_m, const int32_t *ord_n,
+                         const int32_t *ord_type, const int32_t *max_valence, int n_atom_type,
+                         int sulfur_idx, uint8_t *accepted, int32_t *block, uint8_t *keep_atom,
+                         int32_t *status, void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,6 +51,8 @@ _SIGNATURES = {
     'psvae_link_ce_fwd': (_c_int, [_c_int, _c_int, _c_int, _p, _c_int, _p, _p, _p, _p, _p, _p, _p, _p, _c_size, _p]),
     'psvae_link_ce_bwd_input': (_c_int, [_c_int, _c_int, _c_int, _p, _p, _p, _p, _c_int, _p]),
     'psvae_link_infer': (_c_int, [_c_int, _c_int, _p, _c_f32, _c_int, _p, _p, _p, _p]),
+    'psvae_assemble_links_workspace_bytes': (_c_size, [_c_int]),
+    'psvae_assemble_links': (_c_int, [_c_int, _c_int] + [_p] * 12 + [_c_int, _c_int] + [_p] * 5 + [_c_size, _p]),
 }
 
 _lib = None
@@ -388,6 +390,27 @@ def link_infer(logits, add_edge_th, none_bond, conf, etype, keep):
     _check(lib().psvae_link_infer(P, C, ptr(logits, torch.float32), float(add_edge_th), int(none_bond),
                                   ptr(conf, torch.float32), ptr(etype, torch.int32), ptr(keep, torch.uint8),
                                   _stream()), 'psvae_link_infer')
+
+
+def assemble_links(node_off, atom_type, block0, n_blocks, row_ptr, col, cls, order_ptr, ord_m, ord_n, ord_type,
+                   max_valence, sulfur_idx, accepted, block, keep_atom, status):
+    L = lib()
+    i32, u8 = torch.int32, torch.uint8
+    B, V = n_blocks.numel(), atom_type.numel()
+    if node_off.numel() != B + 1 or order_ptr.numel() != B + 1 or row_ptr.numel() != V + 1:
+        raise ValueError('assemble_links: offset arrays do not match B / V')
+    if not (block0.numel() == block.numel() == keep_atom.numel() == V and status.numel() == B):
+        raise ValueError('assemble_links: per-atom / per-molecule array sizes do not match')
+    if not (ord_m.numel() == ord_n.numel() == ord_type.numel() == accepted.numel()):
+        raise ValueError('assemble_links: candidate arrays differ in length')
+    nbytes = L.psvae_assemble_links_workspace_bytes(V)
+    ws = workspace(nbytes, n_blocks.device) if nbytes else None
+    _check(L.psvae_assemble_links(B, V, ptr(node_off, i32), ptr(atom_type, i32), ptr(block0, i32), ptr(n_blocks, i32),
+                                  ptr(row_ptr, i32), ptr(col, i32), ptr(cls, u8), ptr(order_ptr, i32),
+                                  ptr(ord_m, i32), ptr(ord_n, i32), ptr(ord_type, i32), ptr(max_valence, i32),
+                                  max_valence.numel(), int(sulfur_idx), ptr(accepted, u8), ptr(block, i32),
+                                  ptr(keep_atom, u8), ptr(status, i32), ptr(ws), nbytes, _stream()),
+           'psvae_assemble_links')
 
 
 def exclusive_scan(inp, out):

@@ -12,6 +12,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import hip, ops
+from ..utils.chem_vocab import MAX_VALENCE
 from .common_nn import MLP, run_linear, run_sequential
 from .encoder import Encoder
 
@@ -307,6 +308,46 @@ class VAEPieceDecoder(nn.Module):
         order_ptr[1:] = torch.cumsum(torch.bincount(graph[order], minlength=B), 0)
         out.update(conf=conf, etype=etype.to(torch.int64), order=order, order_ptr=order_ptr)
         return out
+
+    @torch.no_grad()
+    def assemble_links_batch(self, links, x, node_off, csr_in, block0, n_blocks):
+        """The greedy bond loop of `inference` (:245-268) for many generated molecules at once:
+        the kept candidates of `links` (the dict infer_links_batch returns) are visited per
+        molecule in confidence order; a bond is added when valence_check and cycle_check
+        (src/utils/chem_utils.py:447-483) allow it, fragments joined by a bond merge into one
+        block and the atoms outside the largest block are marked for removal.
+
+        x [V]: chemical-vocabulary id of every atom; csr_in: ops.Csr of the bonds inside the
+        fragments over the flat atom ids (cls = bond index 1..3); block0 [V]: fragment index
+        of every atom inside its molecule (0 .. n_blocks[b]-1, the order of `groups` at :189);
+        n_blocks [B].
+
+        Returns a dict: accepted [Ek] bool (aligned with links['order']), block [V] (final
+        block id per atom), keep_atom [V] bool, status [B] (0 ok, 1 an atom exceeded 8
+        neighbours, 2 bad ids)."""
+        dev = self.W_mean.weight.device
+        i32 = torch.int32
+        vocab = self.tokenizer.chem_vocab
+        node_off = node_off.to(dev).to(i32).contiguous()
+        B = node_off.numel() - 1
+        order = links['order']
+        ord_m = links['m'][order].to(i32).contiguous()
+        ord_n = links['n'][order].to(i32).contiguous()
+        ord_type = links['etype'][order].to(i32).contiguous()
+        order_ptr = links['order_ptr'].to(i32).contiguous()
+        atom_type = x.to(dev).to(i32).contiguous()
+        V = atom_type.numel()
+        n_atom = len(MAX_VALENCE)
+        max_valence = torch.tensor([MAX_VALENCE[vocab.idx_to_atom(i)] for i in range(n_atom)], dtype=i32, device=dev)
+        accepted = torch.empty(ord_m.numel(), dtype=torch.uint8, device=dev)
+        block = torch.empty(V, dtype=i32, device=dev)
+        keep_atom = torch.empty(V, dtype=torch.uint8, device=dev)
+        status = torch.zeros(B, dtype=i32, device=dev)
+        hip.assemble_links(node_off, atom_type, block0.to(dev).to(i32).contiguous(),
+                           n_blocks.to(dev).to(i32).contiguous(), csr_in.row_ptr, csr_in.col, csr_in.cls,
+                           order_ptr, ord_m, ord_n, ord_type, max_valence, vocab.atom_to_idx('S'),
+                           accepted, block, keep_atom, status)
+        return {'accepted': accepted.bool(), 'block': block, 'keep_atom': keep_atom.bool(), 'status': status}
 
     def inference(self, z, max_atom_num, add_edge_th, temperature):
         raise NotImplementedError(

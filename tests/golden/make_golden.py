@@ -330,7 +330,82 @@ def make_infer():
     np.savez_compressed(os.path.join(HERE, 'infer_links.npz'), **out)
 
 
+class _AdjAtom:
+    """What chem_utils.shortest_path_len asks of an RDKit atom: GetIdx / GetNeighbors."""
+
+    def __init__(self, mol, idx):
+        self.mol, self.idx = mol, idx
+
+    def GetIdx(self):
+        return self.idx
+
+    def GetNeighbors(self):
+        return [_AdjAtom(self.mol, j) for j in self.mol.adj[self.idx]]
+
+
+class _AdjMol:
+    """An adjacency list behind the one RWMol method the reference's cycle_check uses."""
+
+    def __init__(self, adj):
+        self.adj = adj
+
+    def GetAtomWithIdx(self, i):
+        return _AdjAtom(self, i)
+
+
+def make_assemble_checks():
+    """Known answers of the reference's own valence_check / cycle_check
+    (src/utils/chem_utils.py:447-483) on random inputs."""
+    import utils.chem_utils as cu
+    vocab = tok.chem_vocab
+    rng = np.random.default_rng(12)
+    nv = 600
+    v_atoms = rng.choice(10, size=(nv, 2), p=[.04, .03, .35, .03, .03, .02, .15, .1, .1, .15])
+    v_len = rng.integers(0, 4, size=(nv, 2))
+    v_edges = rng.choice([1, 1, 1, 2, 2, 3], size=(nv, 2, 4))
+    v_new = rng.integers(0, 4, size=nv)
+    v_ok = np.zeros(nv, dtype=np.uint8)
+    for k in range(nv):
+        e1 = v_edges[k, 0, :v_len[k, 0]].tolist()
+        e2 = v_edges[k, 1, :v_len[k, 1]].tolist()
+        v_ok[k] = bool(cu.valence_check(int(v_atoms[k, 0]), int(v_atoms[k, 1]), e1, e2, int(v_new[k]), vocab))
+    nc, max_e = 400, 24
+    c_n = np.zeros(nc, dtype=np.int64)
+    c_edges = -np.ones((nc, max_e, 2), dtype=np.int64)
+    c_pair = np.zeros((nc, 2), dtype=np.int64)
+    c_ok = np.zeros(nc, dtype=np.uint8)
+    c_len = np.zeros(nc, dtype=np.int64)   # shortest_path_len, 0 for None
+    for k in range(nc):
+        n = int(rng.integers(2, 15))
+        edges = set()
+        for a in range(1, n):                       # a forest with some roots left unattached
+            if rng.random() < 0.85:
+                edges.add((int(rng.integers(0, a)), a))
+        for _ in range(int(rng.integers(0, 4))):    # a few ring closures
+            a, b = sorted(rng.integers(0, n, size=2).tolist())
+            if a != b:
+                edges.add((a, b))
+        edges = sorted(edges)[:max_e]
+        adj = [[] for _ in range(n)]
+        for a, b in edges:
+            adj[a].append(b), adj[b].append(a)
+        i, j = rng.choice(n, size=2, replace=False).tolist()
+        c_n[k] = n
+        c_edges[k, :len(edges)] = np.asarray(edges, dtype=np.int64).reshape(-1, 2)
+        c_pair[k] = (i, j)
+        mol = _AdjMol(adj)
+        c_ok[k] = bool(cu.cycle_check(i, j, mol))
+        c_len[k] = cu.shortest_path_len(i, j, mol) or 0
+    np.savez_compressed(os.path.join(HERE, 'assemble_checks.npz'), v_atoms=v_atoms, v_len=v_len, v_edges=v_edges,
+                        v_new=v_new, v_ok=v_ok, c_n=c_n, c_edges=c_edges, c_pair=c_pair, c_ok=c_ok, c_len=c_len)
+    print('assemble_checks:', int(v_ok.sum()), 'of', nv, 'valence checks pass;', int(c_ok.sum()), 'of', nc,
+          'cycle checks pass;', int((c_len == 0).sum()), 'unreachable')
+
+
 if __name__ == '__main__':
+    if sys.argv[1:] == ['assemble']:
+        make_assemble_checks()
+        sys.exit(0)
     make_collate()
     small = args_namespace(node_hidden_dim=36, graph_embedding_dim=40, latent_dim=8, atom_embedding_dim=6,
                            piece_embedding_dim=12, pos_embedding_dim=6, piece_hidden_dim=20,
@@ -341,3 +416,4 @@ if __name__ == '__main__':
                seed=2021, store_weights=False)
     make_beta()
     make_infer()
+    make_assemble_checks()

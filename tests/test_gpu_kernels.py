@@ -479,3 +479,99 @@ def test_collate_subset_order_and_large_molecule(tokenizer):
     assert got.num_uniforms == used
     for k in REF_KEYS:
         assert np.array_equal(got[k].cpu().numpy(), want[k]), k
+
+
+# ------------------------------------------------------------------ greedy bond assembly
+def _assembly_case(rng, n_lo, n_hi):
+    """A random fragment set: atoms, bonds inside the fragments, groups, candidates between
+    fragments in a random visiting order with random bond classes (0 = None appears too)."""
+    n = int(rng.integers(n_lo, n_hi + 1))
+    atoms = rng.choice(10, size=n, p=[.02, .02, .6, .02, .03, .01, .12, .1, .02, .06]).tolist()
+    k = int(rng.integers(1, max(2, n // 3) + 1))
+    frag = np.sort(rng.integers(0, k, size=n))
+    _, frag = np.unique(frag, return_inverse=True)
+    groups = [np.nonzero(frag == g)[0].tolist() for g in range(int(frag.max()) + 1)]
+    bonds = []
+    for grp in groups:                        # a chain through each fragment, sometimes closed
+        for a, b in zip(grp[:-1], grp[1:]):
+            bonds.append((a, b, int(rng.choice([1, 1, 1, 2]))))
+        if len(grp) in (5, 6) and rng.random() < 0.5:
+            bonds.append((grp[0], grp[-1], 1))
+    cand = [(i, j) for i in range(n) for j in range(i + 1, n) if frag[i] != frag[j]]
+    ctype = rng.choice([0, 1, 1, 1, 2, 3], size=len(cand)).tolist()
+    take = rng.random(len(cand)) < 0.6
+    order = rng.permutation(np.nonzero(take)[0]).tolist()
+    return atoms, bonds, groups, cand, ctype, order
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,n_lo,n_hi', [(1, 1, 1), (7, 2, 6), (300, 1, 40), (65, 30, 70)])
+def test_assemble_links_vs_oracle(B, n_lo, n_hi, tokenizer):
+    """One lane per molecule against the per-molecule Python loop: accepted flags, final
+    blocks and kept atoms are identical."""
+    from oracle import assemble_ref
+    from ps_vae_amd import hip
+    from ps_vae_amd.utils.chem_vocab import MAX_VALENCE
+    d = dev()
+    rng = np.random.default_rng(1000 + B)
+    vocab = tokenizer.chem_vocab
+    cases = [_assembly_case(rng, n_lo, n_hi) for _ in range(B)]
+    node_off = np.concatenate([[0], np.cumsum([len(c[0]) for c in cases])]).astype(np.int32)
+    V = int(node_off[-1])
+    atom_type = np.concatenate([c[0] for c in cases]).astype(np.int32)
+    block0 = np.zeros(V, dtype=np.int32)
+    n_blocks = np.zeros(B, dtype=np.int32)
+    rows = [[] for _ in range(V)]
+    ord_m, ord_n, ord_t, order_ptr = [], [], [], [0]
+    want_acc, want_block, want_keep = [], [], []
+    for b, (atoms, bonds, groups, cand, ctype, order) in enumerate(cases):
+        o = int(node_off[b])
+        for gi, grp in enumerate(groups):
+            block0[o + np.asarray(grp, dtype=np.int64)] = gi
+        n_blocks[b] = len(groups)
+        for a, e, t in bonds:
+            rows[o + a].append((o + e, t)), rows[o + e].append((o + a, t))
+        for i in order:
+            ord_m.append(cand[i][0]), ord_n.append(cand[i][1]), ord_t.append(ctype[i])
+        order_ptr.append(len(ord_m))
+        acc, blk, keep = assemble_ref.assemble(atoms, bonds, groups, cand, ctype, order, vocab)
+        want_acc += acc
+        want_block += blk
+        want_keep += keep
+    row_ptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
+    col = np.asarray([c for r in rows for c, _ in r], dtype=np.int32)
+    cls = np.asarray([t for r in rows for _, t in r], dtype=np.uint8)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(d)   # noqa: E731
+    K = len(ord_m)
+    accepted = torch.full((K,), 7, dtype=torch.uint8, device=d)
+    block = torch.full((V,), -1, dtype=torch.int32, device=d)
+    keep_atom = torch.full((V,), 7, dtype=torch.uint8, device=d)
+    status = torch.full((B,), -1, dtype=torch.int32, device=d)
+    max_val = torch.tensor([MAX_VALENCE[vocab.idx_to_atom(i)] for i in range(len(MAX_VALENCE))], dtype=torch.int32,
+                           device=d)
+    hip.assemble_links(t(node_off), t(atom_type), t(block0), t(n_blocks), t(row_ptr), t(col), t(cls),
+                       t(np.asarray(order_ptr, dtype=np.int32)), t(np.asarray(ord_m, dtype=np.int32)),
+                       t(np.asarray(ord_n, dtype=np.int32)), t(np.asarray(ord_t, dtype=np.int32)), max_val,
+                       vocab.atom_to_idx('S'), accepted, block, keep_atom, status)
+    torch.cuda.synchronize()
+    assert status.cpu().tolist() == [0] * B
+    assert accepted.cpu().tolist() == [int(v) for v in want_acc]
+    assert block.cpu().tolist() == want_block
+    assert keep_atom.cpu().tolist() == [int(v) for v in want_keep]
+
+
+@pytest.mark.gpu
+def test_assemble_links_rejects_bad_ids(tokenizer):
+    """A block id outside 0..n_blocks-1 is reported in status, not followed."""
+    from ps_vae_amd import hip
+    d = dev()
+    i32 = torch.int32
+    z = lambda n, dt=i32: torch.zeros(n, dtype=dt, device=d)   # noqa: E731
+    node_off = torch.tensor([0, 2], dtype=i32, device=d)
+    block0 = torch.tensor([0, 5], dtype=i32, device=d)
+    status = z(1)
+    acc, blk, keep = z(1, torch.uint8), z(2), z(2, torch.uint8)
+    hip.assemble_links(node_off, z(2) + 2, block0, z(1) + 2, z(3), z(0), z(0, torch.uint8),
+                       torch.tensor([0, 1], dtype=i32, device=d), z(1), z(1) + 1, z(1) + 1,
+                       torch.full((10,), 4, dtype=i32, device=d), 9, acc, blk, keep, status)
+    assert status.item() == 2 and acc.item() == 0 and keep.cpu().tolist() == [0, 0]

@@ -336,6 +336,65 @@ def test_infer_links_batch_equals_per_molecule(tokenizer):
             assert sorted(got) == sorted(order)
 
 
+def test_assemble_links_batch_follows_the_greedy_loop(tokenizer):
+    """infer_links_batch -> assemble_links_batch on 96 synthetic fragment sets: with the
+    candidates, types and visiting order the GPU produced, the accepted bonds, final blocks and
+    kept atoms equal the per-molecule Python loop of the oracle."""
+    from oracle import assemble_ref
+    from ps_vae_amd import ops as hops
+    from ps_vae_amd.data.synthetic import synthetic_step1
+    model, _ = hip_model(tokenizer, seed=3, **SMALL)
+    dec = model.decoder
+    rng = np.random.default_rng(8)
+    latent = dec.latent_dim
+    mols = []
+    for d in synthetic_step1(96, seed=21, shape='zinc'):
+        n = len(d['x'])
+        groups = [g for g in d['groups'] if len(g)]
+        frag = np.zeros(n, dtype=np.int64)
+        for gi, grp in enumerate(groups):
+            frag[grp] = gi
+        bonds = [(a, b, c) for (a, b), c in zip(d['edge_index'], d['edge_attr']) if frag[a] == frag[b]]
+        mols.append(dict(x=np.asarray(d['x']), frag=frag, groups=groups, bonds=bonds,
+                         xp=rng.integers(0, 300, size=n)))
+    node_off = np.concatenate([[0], np.cumsum([len(m['x']) for m in mols])])
+    V = int(node_off[-1])
+    src, dst, cls = [], [], []
+    for m, o in zip(mols, node_off[:-1]):
+        for a, b, c in m['bonds']:
+            src += [o + a, o + b]
+            dst += [o + b, o + a]
+            cls += [c, c]
+    ei = torch.tensor([src, dst], dtype=torch.int64).reshape(2, -1)
+    ea = torch.nn.functional.one_hot(torch.tensor(cls, dtype=torch.int64), 4).to(torch.int64)
+    csr = hops.Csr.from_edge_index(ei.to(dev()), ea.to(dev()), V)
+    x = torch.from_numpy(np.concatenate([m['x'] for m in mols]))
+    frag = torch.from_numpy(np.concatenate([m['frag'] for m in mols]))
+    xp = torch.from_numpy(np.concatenate([m['xp'] for m in mols]))
+    z = torch.from_numpy(rng.standard_normal((len(mols), latent)).astype(np.float32))
+    links = dec.infer_links_batch(z, x, xp, frag, torch.from_numpy(node_off), csr, frag, 0.3)
+    n_blocks = torch.tensor([len(m['groups']) for m in mols])
+    res = dec.assemble_links_batch(links, x, torch.from_numpy(node_off), csr, frag, n_blocks)
+    assert res['status'].cpu().tolist() == [0] * len(mols)
+    ptr, optr = links['ptr'].cpu().numpy(), links['order_ptr'].cpu().numpy()
+    lm, ln, et = links['m'].cpu().numpy(), links['n'].cpu().numpy(), links['etype'].cpu().numpy()
+    order = links['order'].cpu().numpy()
+    acc, blk, keep = res['accepted'].cpu().numpy(), res['block'].cpu().numpy(), res['keep_atom'].cpu().numpy()
+    n_acc = 0
+    for b, m in enumerate(mols):
+        lo, hi = int(ptr[b]), int(ptr[b + 1])
+        cand = list(zip(lm[lo:hi].tolist(), ln[lo:hi].tolist()))
+        srt = (order[optr[b]:optr[b + 1]] - lo).tolist()
+        w_acc, w_blk, w_keep = assemble_ref.assemble(m['x'].tolist(), m['bonds'], m['groups'], cand,
+                                                     et[lo:hi].tolist(), srt, tokenizer.chem_vocab)
+        assert acc[optr[b]:optr[b + 1]].tolist() == w_acc, b
+        a0, a1 = int(node_off[b]), int(node_off[b + 1])
+        assert blk[a0:a1].tolist() == w_blk, b
+        assert keep[a0:a1].tolist() == w_keep, b
+        n_acc += sum(w_acc)
+    assert n_acc > 0
+
+
 def test_process_step3_same_seed_as_reference(tokenizer):
     """BPEMolDataset.process_step3 draws random.random() in the reference's order: under the
     seed the golden batch was made with it must return that batch."""

@@ -169,3 +169,43 @@ def test_compact_layout_consistency(tokenizer):
     sel[c['pair_graph'], local[c['pair_src']], local[c['pair_dst']]] = True
     assert np.array_equal(sel, batch['edge_select'])
     assert len(c['in_col']) == len(batch['in_piece_edge_idx'])
+
+
+def test_assemble_checks_against_reference_answers(tokenizer):
+    """valence_check / cycle_check / shortest_path_len of the restatement give the answers the
+    reference's own functions gave on the same inputs (tests/golden/assemble_checks.npz)."""
+    from oracle import assemble_ref
+    g = load_npz('assemble_checks.npz')
+    vocab = tokenizer.chem_vocab
+    for k in range(len(g['v_ok'])):
+        e1 = g['v_edges'][k, 0, :g['v_len'][k, 0]].tolist()
+        e2 = g['v_edges'][k, 1, :g['v_len'][k, 1]].tolist()
+        got = assemble_ref.valence_check(int(g['v_atoms'][k, 0]), int(g['v_atoms'][k, 1]), e1, e2,
+                                         int(g['v_new'][k]), vocab)
+        assert bool(got) == bool(g['v_ok'][k]), k
+    for k in range(len(g['c_ok'])):
+        n = int(g['c_n'][k])
+        adj = [[] for _ in range(n)]
+        for a, b in g['c_edges'][k]:
+            if a >= 0:
+                adj[a].append(b), adj[b].append(a)
+        i, j = (int(v) for v in g['c_pair'][k])
+        assert (assemble_ref.shortest_path_len(i, j, adj) or 0) == int(g['c_len'][k]), k
+        assert bool(assemble_ref.cycle_check(i, j, adj)) == bool(g['c_ok'][k]), k
+
+
+def test_assemble_loop_small_cases(tokenizer):
+    """The greedy loop on hand-checked cases: a 6-ring closes, a 4-ring does not, a bond that
+    would exceed a valence is refused, blocks merge and the largest survives."""
+    from oracle import assemble_ref
+    vocab = tokenizer.chem_vocab
+    C, O = vocab.atom_to_idx('C'), vocab.atom_to_idx('O')
+    # two 3-atom chains C-C-C: joining 2-3 makes a 6-chain, then 0-5 closes a 6-ring, 1-4 would close a 4-ring
+    atoms = [C] * 6 + [O]
+    bonds = [(0, 1, 1), (1, 2, 1), (3, 4, 1), (4, 5, 1)]
+    groups = [[0, 1, 2], [3, 4, 5], [6]]
+    cand = [(2, 3), (0, 5), (1, 4), (0, 6)]
+    acc, block, keep = assemble_ref.assemble(atoms, bonds, groups, cand, [1, 1, 1, 3], [0, 1, 2, 3], vocab)
+    assert acc == [True, True, False, False]        # 0-6 triple: O allows 2
+    assert block[:6] == [1] * 6 and block[6] == 2
+    assert keep == [True] * 6 + [False]
