@@ -250,12 +250,20 @@ __global__ __launch_bounds__(THREADS, (MASK || WN > 1 || TN > 5) ? 2 : 3) void g
         const int k_live = k_end - k0;   // the last k-tile of a chunk may be partly empty
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
+#ifndef PSVAE_EXP_NOBREAK
             if (kk > 0 && kk >= k_live) break;   // wave-uniform
+#endif
             float a_nxt = 0.f, b_nxt[TN];
             if (kk + 2 < BK) {
+#ifdef PSVAE_EXP_NOLDSREAD   // timing experiment only: wrong results
+                a_nxt = a_cur;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b_nxt[j] = b_cur[j];
+#else
                 a_nxt = a_rd[(kk + 2) * LA::STRIDE];
 #pragma unroll
                 for (int j = 0; j < TN; ++j) b_nxt[j] = b_rd[(kk + 2) * LB::STRIDE + j * 32];
+#endif
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
