@@ -273,6 +273,19 @@ int psvae_link_infer(int P, int C, const float *logits, float add_edge_th, int n
                      float *conf, int32_t *etype, uint8_t *keep, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * First encoder layer on embedding ids.  node_trans (src/modules/encoder.py:54) applied to
+ * embed_atom's concatenated rows (src/modules/vae_piece_decoder.py:65-69) equals
+ * T[x] + T[n_atom + xp] + T[n_atom + n_piece + xq], with T [n_atom + n_piece + n_pos, H] =
+ * the three tables multiplied by the matching column blocks of the weight (bias folded into the
+ * atom rows by the caller).  Writes out [V,H] (row stride ld_out, H and ld_out multiples of 4);
+ * ids outside their table are clamped into it.  The gradient of T is indicator^T g:
+ * psvae_embed_atom_onehot + psvae_gemm_f32.
+ * ---------------------------------------------------------------------------------- */
+int psvae_embed_trans_fwd(int V, int H, const int32_t *x, const int32_t *xp, const int32_t *xq,
+                          int n_atom, int n_piece, int n_pos, const float *T, float *out,
+                          int ld_out, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * Greedy bond assembly of B generated molecules (src/modules/vae_piece_decoder.py:245-270 with
  * valence_check / cycle_check of src/utils/chem_utils.py:447-483), one lane per molecule.
  * Flat per-atom arrays [V] (molecule b owns node_off[b] .. node_off[b+1]): atom_type (chemical

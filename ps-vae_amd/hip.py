@@ -51,6 +51,7 @@ _SIGNATURES = {
     'psvae_link_ce_fwd': (_c_int, [_c_int, _c_int, _c_int, _p, _c_int, _p, _p, _p, _p, _p, _p, _p, _p, _c_size, _p]),
     'psvae_link_ce_bwd_input': (_c_int, [_c_int, _c_int, _c_int, _p, _p, _p, _p, _c_int, _p]),
     'psvae_link_infer': (_c_int, [_c_int, _c_int, _p, _c_f32, _c_int, _p, _p, _p, _p]),
+    'psvae_embed_trans_fwd': (_c_int, [_c_int, _c_int, _p, _p, _p, _c_int, _c_int, _c_int, _p, _p, _c_int, _p]),
     'psvae_assemble_links_workspace_bytes': (_c_size, [_c_int]),
     'psvae_assemble_links': (_c_int, [_c_int, _c_int] + [_p] * 12 + [_c_int, _c_int] + [_p] * 5 + [_c_size, _p]),
 }
@@ -304,6 +305,18 @@ def embed_atom_bwd(x, xp, xq, g, ga, gp, gq):
                                       ptr(g, torch.float32), ga.shape[0], ga.shape[1], gp.shape[0], gp.shape[1],
                                       gq.shape[0], gq.shape[1], ptr(ga, torch.float32), ptr(gp, torch.float32),
                                       ptr(gq, torch.float32), _stream()), 'psvae_embed_atom_bwd')
+
+
+def embed_trans_fwd(x, xp, xq, sizes, T, out):
+    na, npc, nq = sizes
+    po, ldo = _rows(out)
+    if T.shape[0] != na + npc + nq or T.shape[1] != out.shape[1] or not T.is_contiguous():
+        raise ValueError('embed_trans_fwd: T must be a contiguous [n_atom + n_piece + n_pos, H] table')
+    if not (x.numel() == xp.numel() == xq.numel() == out.shape[0]):
+        raise ValueError('embed_trans_fwd: id vectors and output rows differ in length')
+    _check(lib().psvae_embed_trans_fwd(x.numel(), out.shape[1], ptr(x, torch.int32), ptr(xp, torch.int32),
+                                       ptr(xq, torch.int32), na, npc, nq, ptr(T, torch.float32), po, ldo, _stream()),
+           'psvae_embed_trans_fwd')
 
 
 def segment_sum_fwd(x, seg_begin, seg_end, out):

@@ -49,12 +49,21 @@ class Encoder(nn.Module):
                 raise ValueError('edge_attr must be the one-hot [E, num_edge_type] tensor the collation emits')
             csr = ops.Csr.from_edge_index(edge_index, edge_attr, x.shape[0])
         mlp = self.conv.nn.seq
-        if (isinstance(mlp, nn.Sequential) and len(mlp) == 3 and isinstance(mlp[1], nn.ReLU)
-                and mlp[0].bias is not None and mlp[2].bias is not None and self.node_trans.bias is not None):
+        fused = (isinstance(mlp, nn.Sequential) and len(mlp) == 3 and isinstance(mlp[1], nn.ReLU)
+                 and mlp[0].bias is not None and mlp[2].bias is not None and self.node_trans.bias is not None)
+        hidden = self.node_trans.out_features
+        if isinstance(x, ops.EmbeddedIds):
+            if fused and hidden % 4 == 0:
+                # node_trans straight from the embedding ids: no [V, dim_in] rows, no product over them
+                x0 = ops.embed_trans(x, self.node_trans.weight, self.node_trans.bias)
+                all_x = ops.gine_encoder(x0, None, None, self.edge_table(), mlp[0].weight, mlp[0].bias,
+                                         mlp[2].weight, mlp[2].bias, csr, self.t)
+                return all_x[:, (self.t - 1) * hidden:], all_x
+            x = x.rows()
+        if fused:
             # the reference's configuration (MLP(H, H, H, ReLU, 2), encoder.py:48): one fused node
             all_x = ops.gine_encoder(x.float(), self.node_trans.weight, self.node_trans.bias, self.edge_table(),
                                      mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias, csr, self.t)
-            hidden = self.node_trans.out_features
             return all_x[:, (self.t - 1) * hidden:], all_x
         x = run_linear(self.node_trans, x.float())
         table = self.edge_table()

@@ -51,6 +51,16 @@ class VAEPieceDecoder(nn.Module):
             eps = torch.randn_like(z_mean)
         return ops.rsample_kl(z_mean, z_log_var_pre, eps)
 
+    def embedded_ids(self, atom_ids, piece_ids, pos_ids):
+        """The atoms as ids + tables (ops.EmbeddedIds): what embed_atom would return, for
+        encoders that compute their first layer from the ids."""
+        flat = [t.reshape(-1).to(torch.int32) for t in (atom_ids, piece_ids, pos_ids)]
+        ids = ops.EmbeddedIds(flat[0], flat[1], flat[2], self.atom_embedding.weight, self.piece_embedding.weight,
+                              self.pos_embedding.weight)
+        if torch.is_grad_enabled() and flat[0].numel():
+            ids.indicator()   # the backward of both encoders reads it, possibly on two streams
+        return ids
+
     def embed_atom(self, atom_ids, piece_ids, pos_ids):
         """:65-69 — ids of any shape -> [..., atom+piece+pos dims]."""
         shape = atom_ids.shape
@@ -96,6 +106,7 @@ class VAEPieceDecoder(nn.Module):
     def embed_nodes_async(self, node_x, csr):
         """Message passing over the in-piece bonds (:96) on a side stream; returns a handle
         for forward(node_embedding=...), which joins the streams before the first use."""
+        ids = node_x if isinstance(node_x, ops.EmbeddedIds) else None
         main = torch.cuda.current_stream(node_x.device)
         side = _SIDE_STREAMS.get(node_x.device)
         if side is None:
@@ -103,7 +114,8 @@ class VAEPieceDecoder(nn.Module):
         side.wait_stream(main)
         with torch.cuda.stream(side):
             node_embedding, _ = self.graph_embedding.embed_node(node_x, csr, None)
-        node_x.record_stream(side)
+        for t in (ids.tensors() if ids is not None else (node_x,)):
+            t.record_stream(side)
         return node_embedding, side
 
     def forward(self, x, x_pieces, x_pos, edge_index, edge_attr, pieces, conds, edge_select, golden_edge,
@@ -134,8 +146,7 @@ class VAEPieceDecoder(nn.Module):
             for t in (z_vecs, pieces, gold_piece):
                 t.record_stream(side)
         else:
-            node_dim = x.shape[-1]
-            node_x = x.reshape(-1, node_dim)
+            node_x = x if isinstance(x, ops.EmbeddedIds) else x.reshape(-1, x.shape[-1])
             node_embedding, _ = self.graph_embedding.embed_node(node_x, edge_index, edge_attr)
         pairs = edge_select if isinstance(edge_select, ops.PairList) else ops.PairList.from_edge_select(edge_select)
         golden = golden_edge if golden_edge.dtype == torch.int32 else golden_edge.to(torch.int32)

@@ -200,16 +200,22 @@ class _GineEncoder(Function):
 
     @staticmethod
     def forward(ctx, x_in, w0, b0, table, w1, b1, w2, b2, csr, t):
+        """w0 None: x_in [V,H] already is node_trans' output (see embed_trans)."""
         x_in = _rows2d(x_in)
         V, Din = x_in.shape
-        H = w0.shape[0]
+        H = w1.shape[1]
         dev = x_in.device
-        w0, w1, w2, table = w0.contiguous(), w1.contiguous(), w2.contiguous(), table.contiguous()
-        x0 = torch.empty(V, H, dtype=torch.float32, device=dev)
+        w1, w2, table = w1.contiguous(), w2.contiguous(), table.contiguous()
         all_x = torch.empty(V, t * H, dtype=torch.float32, device=dev)
         a = torch.empty(t, V, H, dtype=torch.float32, device=dev)
         h = torch.empty(t, V, H, dtype=torch.float32, device=dev)
-        hip.gemm(V, H, Din, x_in, _ld(x_in), 1, w0, 1, Din, x0, H, bias=b0)
+        if w0 is None:
+            x0 = x_in if (x_in.dtype == torch.float32 and x_in.is_contiguous()) else x_in.float().contiguous()
+            x_in = None
+        else:
+            w0 = w0.contiguous()
+            x0 = torch.empty(V, H, dtype=torch.float32, device=dev)
+            hip.gemm(V, H, Din, x_in, _ld(x_in), 1, w0, 1, Din, x0, H, bias=b0)
         prev = x0
         for i in range(t):
             hip.gine_aggregate_fwd(prev, table, csr.row_ptr, csr.col, csr.cls, a[i])
@@ -227,9 +233,8 @@ class _GineEncoder(Function):
     def backward(ctx, g_all):
         x_in, w0, table, w1, w2, x0, all_x, a, h = ctx.saved_tensors
         csr, t = ctx.csr, ctx.t
-        V, Din = x_in.shape
-        H = w0.shape[0]
-        dev = x_in.device
+        V, H = x0.shape
+        dev = x0.device
         g_all = g_all if (g_all.dtype == torch.float32 and g_all.is_contiguous()) else g_all.float().contiguous()
         f32 = dict(dtype=torch.float32, device=dev)
         gx = torch.empty(t, V, H, **f32)      # dL/d x_i (output of layer i), stacked for the dW2 product
@@ -256,6 +261,9 @@ class _GineEncoder(Function):
         gx2, gh2, h2, a2 = gx.view(TV, H), gh.view(TV, H), h.view(TV, H), a.view(TV, H)
         hip.gemm(H, H, TV, gx2, 1, H, h2, H, 1, gw2, H, split_k=0, rowsum=gb2)
         hip.gemm(H, H, TV, gh2, 1, H, a2, H, 1, gw1, H, split_k=0, rowsum=gb1)
+        if w0 is None:
+            return g_x0, None, None, g_table, gw1, gb1, gw2, gb2, None, None
+        Din = x_in.shape[1]
         gw0, gb0 = torch.empty_like(w0), torch.empty(H, **f32)
         hip.gemm(H, Din, V, g_x0, 1, H, x_in, _ld(x_in), 1, gw0, Din, split_k=0, rowsum=gb0)
         g_in = None
@@ -305,6 +313,85 @@ class _EmbedAtom(Function):
 def embed_atom(x, xp, xq, e_atom, e_piece, e_pos):
     """[E_atom[x] | E_piece[xp] | E_pos[xq]] for flat int32 id vectors -> [V, D]."""
     return _EmbedAtom.apply(x, xp, xq, e_atom, e_piece, e_pos)
+
+
+# ------------------------------------------------------------------------ first encoder layer on ids
+class EmbeddedIds:
+    """The atoms of a batch as embedding ids plus the three tables, standing for the rows
+    embed_atom would produce (src/modules/vae_piece_decoder.py:65-69).  Encoder.embed_node
+    accepts it in place of those rows and computes node_trans from the ids (embed_trans)."""
+
+    def __init__(self, x, xp, xq, e_atom, e_piece, e_pos):
+        self.x, self.xp, self.xq = x, xp, xq
+        self.tables = (e_atom, e_piece, e_pos)
+
+    @property
+    def shape(self):
+        return (self.x.numel(), sum(t.shape[1] for t in self.tables))
+
+    @property
+    def device(self):
+        return self.x.device
+
+    def rows(self):
+        """The embedded rows themselves, [V, D]."""
+        return embed_atom(self.x, self.xp, self.xq, *self.tables)
+
+    def tensors(self):
+        """Every device buffer this object owns (for record_stream on a second stream)."""
+        ind = getattr(self, '_indicator', None)
+        return (self.x, self.xp, self.xq) + ((ind,) if ind is not None else ())
+
+    def indicator(self):
+        """[V, R4] f32, a one in the three key columns of every atom (R4 = table rows rounded
+        up to 4); built once per batch and shared by the backward of every encoder.  Call it
+        on the stream that created the ids BEFORE work forks to other streams: a backward on
+        another stream only reads it."""
+        if getattr(self, '_indicator', None) is None:
+            sizes = [int(t.shape[0]) for t in self.tables]
+            r4 = (sum(sizes) + 3) // 4 * 4
+            onehot = torch.empty(self.x.numel(), r4, dtype=torch.float32, device=self.x.device)
+            hip.embed_atom_onehot(self.x, self.xp, self.xq, sizes[0], sizes[1], sizes[2], onehot)
+            self._indicator = onehot
+        return self._indicator
+
+
+class _EmbedTrans(Function):
+    @staticmethod
+    def forward(ctx, T, ids):
+        T = T.contiguous()
+        out = torch.empty(ids.x.numel(), T.shape[1], dtype=torch.float32, device=T.device)
+        hip.embed_trans_fwd(ids.x, ids.xp, ids.xq, tuple(int(t.shape[0]) for t in ids.tables), T, out)
+        ctx.ids, ctx.rows = ids, T.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        # dT = indicator^T g: deterministic (split-K in fixed order), one product per encoder
+        g2 = g if (g.dtype == torch.float32 and g.is_contiguous()) else g.float().contiguous()
+        V, H = g2.shape
+        if V == 0:
+            return torch.zeros(ctx.rows, H, dtype=torch.float32, device=g2.device), None
+        onehot = ctx.ids.indicator()
+        r4 = onehot.shape[1]
+        full = torch.empty(r4, H, dtype=torch.float32, device=g2.device)
+        hip.gemm(r4, H, V, onehot, 1, r4, g2, H, 1, full, H, split_k=0)
+        return full[:ctx.rows], None
+
+
+def embed_trans(ids, weight, bias):
+    """node_trans(embed_atom(ids)) without the embedded rows (src/modules/encoder.py:54 over
+    src/modules/vae_piece_decoder.py:65-69): T = the tables times the matching column blocks of
+    `weight` (three small products, bias folded into the atom rows, every atom having exactly
+    one), then T[x] + T[n_atom + xp] + T[n_atom + n_piece + xq] per atom."""
+    parts, col = [], 0
+    for i, tab in enumerate(ids.tables):
+        d = tab.shape[1]
+        parts.append(linear(tab, weight[:, col:col + d], bias if i == 0 else None))
+        col += d
+    if col != weight.shape[1]:
+        raise ValueError(f'embedding widths sum to {col}, node_trans expects {weight.shape[1]}')
+    return _EmbedTrans.apply(torch.cat(parts, dim=0), ids)
 
 
 # ------------------------------------------------------------------------ segment sum

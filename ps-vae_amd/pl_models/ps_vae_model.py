@@ -52,7 +52,8 @@ class PSVAEModel(nn.Module):
     def forward(self, batch, return_accu=False, eps=None):
         compact = getattr(batch, 'compact', None)
         if compact is not None:
-            x = self.decoder.embed_atom(compact.cx, compact.cxp, compact.cxpos)          # [V, D]
+            # ids + tables instead of the embedded rows [V, D]: both encoders take their first layer from them
+            x = self.decoder.embedded_ids(compact.cx, compact.cxp, compact.cxpos)
             # The decoder's message passing over the in-piece bonds depends only on x: it runs on
             # a second stream beside the encoder (and so does its backward), so that one
             # chain's HBM-bound aggregations and tile write-outs fill the gaps of the other's

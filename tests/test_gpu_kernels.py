@@ -203,6 +203,49 @@ def test_embed_atom_fwd_bwd():
         close(t.grad, r.grad, rel=2e-5, what=f'd embed / d {name} table')
 
 
+@pytest.mark.parametrize('V,H,sizes', [(1, 4, (2, 3, 1)), (700, 300, (11, 302, 50)), (5001, 36, (11, 302, 50)),
+                                        (40000, 300, (11, 302, 50))])
+def test_embed_trans_fwd(V, H, sizes):
+    """Gather-sum of three table rows per atom against float64 index arithmetic."""
+    from ps_vae_amd import hip
+    d = dev()
+    g = torch.Generator().manual_seed(V + H)
+    na, npc, nq = sizes
+    x = torch.randint(0, na, (V,), generator=g, dtype=torch.int32)
+    xp = torch.randint(0, npc, (V,), generator=g, dtype=torch.int32)
+    xq = torch.randint(0, nq, (V,), generator=g, dtype=torch.int32)
+    T = torch.randn(na + npc + nq, H, generator=g)
+    out = torch.empty(V, H, device=d)
+    hip.embed_trans_fwd(x.to(d), xp.to(d), xq.to(d), sizes, T.to(d), out)
+    T64 = T.double()
+    want = T64[x.long()] + T64[na + xp.long()] + T64[na + npc + xq.long()]
+    close(out, want, what='embed_trans forward')
+
+
+def test_embed_trans_equals_node_trans_of_embedded_rows():
+    """ops.embed_trans(ids, W, b) == Linear(W, b)(embed_atom(ids)) and so are the gradients of
+    the three tables, W and b (float64 yardstick)."""
+    from ps_vae_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(77)
+    V, H, dims, sizes = 3000, 300, (50, 100, 50), (11, 302, 50)
+    ids = [torch.randint(0, n, (V,), generator=g, dtype=torch.int32) for n in sizes]
+    tabs = [torch.randn(n, dd, generator=g) for n, dd in zip(sizes, dims)]
+    W = torch.randn(H, sum(dims), generator=g) * 0.1
+    b = torch.randn(H, generator=g)
+    gout = torch.randn(V, H, generator=g)
+    leaves = [t.clone().to(d).requires_grad_(True) for t in tabs + [W, b]]
+    out = ops.embed_trans(ops.EmbeddedIds(*[i.to(d) for i in ids], *leaves[:3]), leaves[3], leaves[4])
+    out.backward(gout.to(d))
+    ref = [t.clone().double().requires_grad_(True) for t in tabs + [W, b]]
+    rows = torch.cat([ref[k][ids[k].long()] for k in range(3)], dim=1)
+    want = rows @ ref[3].t() + ref[4]
+    want.backward(gout.double())
+    close(out, want, what='embed_trans vs Linear(embed_atom)')
+    for got, w, name in zip(leaves, ref, ['E_atom', 'E_piece', 'E_pos', 'W', 'b']):
+        close(got.grad, w.grad, rel=2e-5, what=f'd/d{name}')
+
+
 def test_segment_sum_fwd_bwd():
     from ps_vae_amd import ops
     d = dev()
