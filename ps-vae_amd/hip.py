@@ -84,8 +84,18 @@ def _check(rc, name):
         raise RuntimeError(f'{name} failed with status {rc}: {msg}')
 
 
+try:   # raw handle of PyTorch's current stream without building a torch.cuda.Stream object per launch
+    _raw_stream = torch._C._cuda_getCurrentRawStream
+    _cur_device = torch._C._cuda_getDevice
+except AttributeError:   # other PyTorch builds: the public (slower) route
+    def _raw_stream(index):
+        return torch.cuda.current_stream(index).cuda_stream
+
+    _cur_device = torch.cuda.current_device
+
+
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(_raw_stream(_cur_device()))
 
 
 def ptr(t, dtype=None):
@@ -112,7 +122,8 @@ _workspaces = {}
 def workspace(nbytes, device):
     """A scratch buffer per (device, stream), grown on demand.  Kernels that reuse it are
     ordered by the stream they are enqueued on; two streams never share one."""
-    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    index = device.index if device.index is not None else _cur_device()
+    key = (index, _raw_stream(index))
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)

@@ -37,6 +37,7 @@ class PSVAEModel(nn.Module):
         self.logged = {}
         # compact path only; PSVAE_STREAMS=1 keeps everything on the current stream
         self.two_streams = os.environ.get('PSVAE_STREAMS', '2') != '1'
+        self.two_streams_min_nodes = 32768   # atoms in the batch from which the fork pays (measured)
         if self.two_streams:
             # parameters of the side-stream chain receive their gradients on that stream; autograd
             # orders the accumulation correctly and says so once per process
@@ -58,7 +59,9 @@ class PSVAEModel(nn.Module):
             # a second stream beside the encoder (and so does its backward), so that one
             # chain's HBM-bound aggregations and tile write-outs fill the gaps of the other's
             # matrix products.
-            node_embedding = self.decoder.embed_nodes_async(x, compact.csr_in) if self.two_streams else None
+            # (small batches are bound by the host's launch rate, where a second stream only adds joins)
+            fork = self.two_streams and compact.num_nodes >= self.two_streams_min_nodes
+            node_embedding = self.decoder.embed_nodes_async(x, compact.csr_in) if fork else None
             _, all_x = self.encoder.embed_node(x, compact.csr)
             graph_embedding = self.encoder.embed_graph(all_x, compact.segments)
             batch_size = compact.num_graphs

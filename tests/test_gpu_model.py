@@ -148,6 +148,7 @@ def test_default_width_batch_256_against_oracle(tokenizer):
     ref = model_ref.PSVAEModel(cfg, tokenizer)
     ref64 = copy.deepcopy(ref).double()
     model, _ = hip_model(tokenizer, state=ref.state_dict())
+    model.two_streams_min_nodes = 0          # exercise the two-stream schedule at this batch size too
     eps = torch.randn(B, 56, generator=torch.Generator().manual_seed(2))
     tb = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in want_batch.items()}
     pl, (rec, piece, edge, kl) = ref(tb, eps)
