@@ -41,7 +41,7 @@ def parse():
                     help='GPU index for every rank (rehearsal of N ranks on one GPU); default LOCAL_RANK')
     ap.add_argument('--gemm-shapes', action='store_true', help='per-shape GEMM timing table on stderr')
     ap.add_argument('--cpu-batch', type=int, default=256)
-    ap.add_argument('--cpu-steps', type=int, default=3)
+    ap.add_argument('--cpu-steps', type=int, default=40, help='CPU-baseline sample: about 10 s of host work')
     return ap.parse_args()
 
 

@@ -66,3 +66,58 @@ def test_ops_refuse_cpu_tensors():
     import torch
     with pytest.raises(RuntimeError):
         hip.ptr(torch.zeros(4))
+
+
+def test_rejected_arguments_return_codes_without_touching_the_gpu():
+    """Argument checks run before any launch: bad sizes, null pointers, short workspaces and
+    unsupported shapes come back as negative status codes with a message, and empty problems
+    return 0.  (Pointers here are never dereferenced: every call returns from its checks.)"""
+    if not os.path.exists(hip.LIB_PATH):
+        pytest.fail(f'{hip.LIB_PATH} not built (run __graft_entry__.build())')
+    L = hip.lib()
+    EINVAL, ETOOLARGE, EWORKSPACE = -1, -2, -3
+    P = ctypes.c_void_p(4096)          # a non-null, 16-byte aligned stand-in
+    null = None
+
+    def gemm(M, N, K, A=P, B=P, C=P, ldc=None, split_k=1, ws=null, ws_bytes=0, act=0):
+        return L.psvae_gemm_f32(M, N, K, A, null, K, 1, B, 1, K, C, N if ldc is None else ldc, null, null, null, act,
+                                0, split_k, ws, ws_bytes, null)
+
+    assert gemm(0, 8, 8) == 0 and gemm(8, 0, 8) == 0                  # empty output: nothing to do
+    assert gemm(-1, 8, 8) == EINVAL
+    assert gemm(8, 8, 8, C=null) == EINVAL
+    assert gemm(8, 8, 8, A=null) == EINVAL
+    assert gemm(8, 8, 8, ldc=4) == EINVAL
+    assert gemm(8, 8, 8, act=7) == EINVAL
+    assert gemm(64, 64, 4096, split_k=4) == EWORKSPACE               # split-K without its workspace
+    assert b'workspace' in L.psvae_last_error()
+    assert L.psvae_gemm_f32_workspace_bytes(64, 64, 4096, 4) >= 4 * 64 * 64 * 4
+    assert L.psvae_gemm_f32_workspace_bytes(64, 64, 4096, 1) == 0
+
+    # first encoder layer from ids: widths must be multiples of 4, tables non-empty
+    et = L.psvae_embed_trans_fwd
+    assert et(0, 300, null, null, null, 11, 302, 50, P, P, 300, null) == 0
+    assert et(5, 302, P, P, P, 11, 302, 50, P, P, 304, null) == EINVAL
+    assert et(5, 300, P, P, P, 11, 302, 50, P, P, 296, null) == EINVAL
+    assert et(5, 300, P, P, P, 0, 302, 50, P, P, 300, null) == EINVAL
+    assert et(5, 300, null, P, P, 11, 302, 50, P, P, 300, null) == EINVAL
+    assert et(5, 300, P, P, P, 11, 302, 50, ctypes.c_void_p(4100), P, 300, null) == EINVAL   # misaligned table
+
+    # greedy assembly: sizes, null arrays, workspace
+    need = L.psvae_assemble_links_workspace_bytes(100)
+    assert need == 100 * (8 + 6) * 4 and L.psvae_assemble_links_workspace_bytes(0) == 0
+
+    def assemble(B, V, ws=P, ws_bytes=need, node_off=P, n_atom_type=10):
+        return L.psvae_assemble_links(B, V, node_off, P, P, P, P, P, P, P, P, P, P, P, n_atom_type, 9, P, P, P, P, ws,
+                                      ws_bytes, null)
+
+    assert assemble(0, 0) == 0
+    assert assemble(-1, 0) == EINVAL
+    assert assemble(4, 100, n_atom_type=0) == EINVAL
+    assert assemble(4, 100, node_off=null) == EINVAL
+    assert assemble(4, 100, ws_bytes=need - 1) == EWORKSPACE
+    assert assemble(4, 100, ws=null) == EWORKSPACE
+
+    # link loss / inference helpers
+    assert L.psvae_link_infer(0, 4, null, 0.5, 0, null, null, null, null) == 0
+    assert ETOOLARGE == -2
