@@ -115,11 +115,23 @@ __global__ __launch_bounds__(1024) void rsample_kl_fwd_kernel(int B, int L, cons
     __shared__ float sh[1024];
     const int total = B * L;
     float s = 0.f;
-    for (int i = threadIdx.x; i < total; i += 1024) {
-        const float m = mean[i];
-        const float lv = -fabsf(lv_pre[i]);
-        s += 1.0f + lv - m * m - expf(lv);
-        z[i] = m + expf(lv / 2) * eps[i];
+    constexpr int U = 8;   // loads in flight per thread: the single workgroup is latency-bound
+    for (int i0 = threadIdx.x; i0 < total; i0 += 1024 * U) {
+        float m[U], pre[U], e[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = min(i0 + 1024 * u, total - 1);
+            m[u] = mean[i], pre[u] = lv_pre[i], e[u] = eps[i];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + 1024 * u;
+            if (i < total) {
+                const float lv = -fabsf(pre[u]);
+                s += 1.0f + lv - m[u] * m[u] - expf(lv);
+                z[i] = m[u] + expf(lv / 2) * e[u];
+            }
+        }
     }
     sh[threadIdx.x] = s;
     __syncthreads();
@@ -255,23 +267,23 @@ __global__ void pair_gather_bwd_kernel(int h4, int l4, int slots, const float4 *
 
 // ---------------------------------------------------------------- two stacked Linears as one
 // W_eff = W_last W_out, b_eff = W_last b_out + b_last (no activation between the layers).
-// Thread (kq, jg) of a workgroup sums j = jg, jg+8, ... for column k = 32*blockIdx.x + kq and
-// all classes; the 8 partial sums are added in jg order through LDS.  The bias is the virtual
+// Thread (kq, jg) of a workgroup sums j = jg, jg+32, ... for column k = 32*blockIdx.x + kq and
+// all classes; the 32 partial sums are added in jg order through LDS.  The bias is the virtual
 // column k == K.
 template <int MAXC>
-__global__ __launch_bounds__(256) void affine_merge_fwd_kernel(int C, int J, int K, const float *__restrict__ w_last,
+__global__ __launch_bounds__(1024) void affine_merge_fwd_kernel(int C, int J, int K, const float *__restrict__ w_last,
                                                                const float *__restrict__ b_last,
                                                                const float *__restrict__ w_out,
                                                                const float *__restrict__ b_out,
                                                                float *__restrict__ w_eff, float *__restrict__ b_eff) {
-    __shared__ float sh[8][MAXC][32];
+    __shared__ float sh[32][MAXC][32];
     const int kq = threadIdx.x & 31, jg = threadIdx.x >> 5;
     const int k = blockIdx.x * 32 + kq;
     float acc[MAXC];
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) acc[c] = 0.f;
     if (k <= K)
-        for (int j = jg; j < J; j += 8) {
+        for (int j = jg; j < J; j += 32) {
             const float w = k < K ? w_out[(long long)j * K + k] : (b_out ? b_out[j] : 0.f);
 #pragma unroll
             for (int c = 0; c < MAXC; ++c)
@@ -286,7 +298,7 @@ __global__ __launch_bounds__(256) void affine_merge_fwd_kernel(int C, int J, int
             if (c < C) {
                 float t = sh[0][c][kq];
 #pragma unroll
-                for (int q = 1; q < 8; ++q) t += sh[q][c][kq];
+                for (int q = 1; q < 32; ++q) t += sh[q][c][kq];
                 if (k < K)
                     w_eff[c * K + k] = t;
                 else
@@ -430,12 +442,20 @@ __global__ __launch_bounds__(256) void link_ce_fwd_kernel(int P, int F, int C, c
 __global__ void link_ce_finish_kernel(int P, int n_part, const float *__restrict__ part_loss,
                                       const int *__restrict__ part_ok, float *__restrict__ loss,
                                       int32_t *__restrict__ n_correct) {
+    __shared__ float sh_s[256];
+    __shared__ int sh_ok[256];
+    float s = 0.f;
+    int ok = 0;
+    for (int i = threadIdx.x; i < n_part; i += 256) s += part_loss[i], ok += part_ok[i];
+    sh_s[threadIdx.x] = s, sh_ok[threadIdx.x] = ok;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {   // fixed order: the same sum on every run
+        if (threadIdx.x < d) sh_s[threadIdx.x] += sh_s[threadIdx.x + d], sh_ok[threadIdx.x] += sh_ok[threadIdx.x + d];
+        __syncthreads();
+    }
     if (threadIdx.x == 0) {
-        float s = 0.f;
-        int ok = 0;
-        for (int i = 0; i < n_part; ++i) s += part_loss[i], ok += part_ok[i];
-        *loss = s / (float)P;   // 0/0 = NaN for P == 0, as torch's mean over no rows
-        if (n_correct) *n_correct = ok;
+        *loss = sh_s[0] / (float)P;   // 0/0 = NaN for P == 0, as torch's mean over no rows
+        if (n_correct) *n_correct = sh_ok[0];
     }
 }
 
@@ -673,10 +693,10 @@ extern "C" int psvae_affine_merge_fwd(int C, int J, int K, const float *w_last, 
     PSVAE_REQUIRE(w_last && w_out && w_eff && b_eff, PSVAE_EINVAL, "psvae_affine_merge_fwd: null pointer");
     const dim3 grid(psvae_cdiv(K + 1, 32));
     if (C <= 4)
-        hipLaunchKernelGGL(affine_merge_fwd_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, C, J, K, w_last, b_last,
+        hipLaunchKernelGGL(affine_merge_fwd_kernel<4>, grid, dim3(1024), 0, (hipStream_t)stream, C, J, K, w_last, b_last,
                            w_out, b_out, w_eff, b_eff);
     else
-        hipLaunchKernelGGL(affine_merge_fwd_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, C, J, K, w_last, b_last,
+        hipLaunchKernelGGL(affine_merge_fwd_kernel<8>, grid, dim3(1024), 0, (hipStream_t)stream, C, J, K, w_last, b_last,
                            w_out, b_out, w_eff, b_eff);
     PSVAE_CHECK_LAUNCH("psvae_affine_merge_fwd");
     return PSVAE_OK;
@@ -738,7 +758,7 @@ extern "C" int psvae_link_ce_fwd(int P, int F, int C, const float *hid, int ldhi
     }
 #undef PSVAE_LINK_CE
     PSVAE_CHECK_LAUNCH("psvae_link_ce_fwd");
-    hipLaunchKernelGGL(link_ce_finish_kernel, dim3(1), dim3(64), 0, s, P, blocks, part_loss, part_ok, loss, n_correct);
+    hipLaunchKernelGGL(link_ce_finish_kernel, dim3(1), dim3(256), 0, s, P, blocks, part_loss, part_ok, loss, n_correct);
     PSVAE_CHECK_LAUNCH("psvae_link_ce_fwd (finish)");
     return PSVAE_OK;
 }
