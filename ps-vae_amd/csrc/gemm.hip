@@ -296,8 +296,28 @@ __global__ __launch_bounds__(THREADS, (MASK || WN > 1 || TN > 5) ? 2 : 3) void g
     float *out = split ? g.ws + (long long)z * g.M * g.ws_ld : g.C;
     const long long ld = split ? g.ws_ld : g.ldc;
     if (g.c_vec) {
+        // A wait for a load also waits for every store issued before it (one in-order counter), and a
+        // store takes microseconds to be acknowledged while the chip is writing C.  So every
+        // value the epilogue reads from memory is requested BEFORE the stores it would queue
+        // behind: all bias vectors ahead of the first store, and a tile's old C / gate rows ahead
+        // of that tile's stores.  The empty asm statements consume the loaded registers, which
+        // pins the wait to that point instead of one wait per store further down.
         float *patch = smem + wave * 32 * EPI_STRIDE;
         const int prow = lane >> 3, pc4 = (lane & 7) * 4;
+        const bool use_bias = !split && g.bias != nullptr;
+        const bool use_old = !split && g.accumulate, use_gate = !split && g.cmask != nullptr;
+        float4 bias4[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + (wave_n * TN + j) * 32 + pc4;
+            bias4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (use_bias && col < g.N) bias4[j] = *reinterpret_cast<const float4 *>(g.bias + col);
+        }
+        if (use_bias) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                asm volatile("" : "+v"(bias4[j].x), "+v"(bias4[j].y), "+v"(bias4[j].z), "+v"(bias4[j].w));
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int cbase = n0 + (wave_n * TN + j) * 32;
@@ -305,10 +325,25 @@ __global__ __launch_bounds__(THREADS, (MASK || WN > 1 || TN > 5) ? 2 : 3) void g
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 patch[((r & 3) + 8 * (r >> 2) + 4 * lhi) * EPI_STRIDE + l31] = acc[j][r];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const int col = cbase + pc4;
-            float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (!split && g.bias && col < g.N) bias4 = *reinterpret_cast<const float4 *>(g.bias + col);
+            float4 old4[4], gate4[4];
+            if (use_old || use_gate) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = m0 + wave_m * 32 + prow + 8 * i;
+                    const bool in = row < g.M && col < g.N;
+                    const long long off = in ? (long long)row * ld + col : 0;
+                    old4[i] = gate4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (use_old) old4[i] = *reinterpret_cast<const float4 *>(out + off);
+                    if (use_gate) gate4[i] = *reinterpret_cast<const float4 *>(g.cmask + off);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    asm volatile("" : "+v"(old4[i].x), "+v"(old4[i].y), "+v"(old4[i].z), "+v"(old4[i].w));
+                    asm volatile("" : "+v"(gate4[i].x), "+v"(gate4[i].y), "+v"(gate4[i].z), "+v"(gate4[i].w));
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = m0 + wave_m * 32 + prow + 8 * i;
@@ -323,20 +358,20 @@ __global__ __launch_bounds__(THREADS, (MASK || WN > 1 || TN > 5) ? 2 : 3) void g
                     float *rs = g.rowsum + row;
                     *rs = g.accumulate ? *rs + v.x : v.x;
                 } else {
-                    v.x += bias4.x, v.y += bias4.y, v.z += bias4.z, v.w += bias4.w;
+                    const float4 b4 = bias4[j];
+                    v.x += b4.x, v.y += b4.y, v.z += b4.z, v.w += b4.w;
                     if (g.act == PSVAE_ACT_RELU)
                         v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
-                    float4 *dst = reinterpret_cast<float4 *>(out + (long long)row * ld + col);
-                    if (g.accumulate) {
-                        const float4 o = *dst;
+                    if (use_old) {
+                        const float4 o = old4[i];
                         v.x += o.x, v.y += o.y, v.z += o.z, v.w += o.w;
                     }
-                    if (g.cmask) {
-                        const float4 mk = *reinterpret_cast<const float4 *>(g.cmask + (long long)row * ld + col);
+                    if (use_gate) {
+                        const float4 mk = gate4[i];
                         v.x = mk.x > 0.f ? v.x : 0.f, v.y = mk.y > 0.f ? v.y : 0.f;
                         v.z = mk.z > 0.f ? v.z : 0.f, v.w = mk.w > 0.f ? v.w : 0.f;
                     }
-                    *dst = v;
+                    *reinterpret_cast<float4 *>(out + (long long)row * ld + col) = v;
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // patch is rewritten by the next tile
