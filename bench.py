@@ -206,7 +206,7 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
             'data': 'synthetic ZINC-shaped molecules (~23 atoms, ~24 bonds), random-init weights',
-            'config': {'workload': 'BASELINE.json configs[2]: synthetic ZINC-shaped graphs, batch 4096 per GPU, '
+            'config': {'workload': f'BASELINE.json configs[2]: synthetic ZINC-shaped graphs, batch {B} per GPU, '
                                    'full train step (GPU collation + encoder + latent + link predictor + piece LM '
                                    '+ backward + all-reduce + clip + Adam)',
                        'batch_per_gpu': B, 'global_batch': B * world, 'parallelism': f'dp{world}',
