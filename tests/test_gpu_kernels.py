@@ -524,6 +524,46 @@ def test_collate_subset_order_and_large_molecule(tokenizer):
         assert np.array_equal(got[k].cpu().numpy(), want[k]), k
 
 
+def test_collate_largest_molecule_and_limits(tokenizer):
+    """250 atoms is the largest molecule the collation kernels take (its n x n byte matrix fills
+    the 64 KB of LDS): bit-exact against the oracle beside small molecules; 251 atoms and an
+    insufficient uniform stream are refused on the host before anything is launched."""
+    from ps_vae_amd.data.collate import collate_packed
+    from ps_vae_amd.data.packed import PackedMolecules
+    from ps_vae_amd.data.synthetic import random_molecule, synthetic_step1
+    d = dev()
+    rng = np.random.default_rng(4)
+    step1 = synthetic_step1(3, seed=8, shape='qm9') + [random_molecule(rng, 250), random_molecule(rng, 251)]
+    packed = PackedMolecules.from_step1(step1)
+    dp = packed.to_device(d)
+    uniforms = np.random.default_rng(10).random(int(packed.n_rng.sum()) + 4)
+    ids = [3, 0, 1, 2]
+    want, used = collate_ref.collate([step1[i] for i in ids], uniforms, piece_pad=tokenizer.pad_idx())
+    got = collate_packed(dp, ids, uniforms=torch.from_numpy(uniforms).to(d), atom_pad=tokenizer.atom_pad_idx(),
+                         piece_pad=tokenizer.pad_idx())
+    assert got.num_uniforms == used and got['x'].shape[1] == 250
+    for k in REF_KEYS:
+        assert np.array_equal(got[k].cpu().numpy(), want[k]), k
+    with pytest.raises(ValueError, match='251 atoms'):
+        collate_packed(dp, [4], uniforms=torch.from_numpy(uniforms).to(d))
+    with pytest.raises(ValueError, match='uniforms needed'):
+        collate_packed(dp, ids, uniforms=torch.from_numpy(uniforms[:10]).to(d))
+
+
+def test_collate_empty_batch(tokenizer):
+    """No molecules: every tensor of both layouts comes back with zero rows."""
+    from ps_vae_amd.data.collate import collate_packed
+    from ps_vae_amd.data.packed import PackedMolecules
+    from ps_vae_amd.data.synthetic import synthetic_step1
+    packed = PackedMolecules.from_step1(synthetic_step1(2, seed=8, shape='qm9'))
+    got = collate_packed(packed.to_device(dev()), [], atom_pad=tokenizer.atom_pad_idx(), piece_pad=tokenizer.pad_idx())
+    torch.cuda.synchronize()
+    assert got.batch_size == 0 and got['x'].shape == (0, 0) and got['edge_index'].shape == (2, 0)
+    assert got['golden_edge'].numel() == 0 and got['edge_select'].numel() == 0
+    c = got.compact
+    assert c.num_nodes == 0 and len(c.pairs) == 0 and c.csr.row_ptr.cpu().tolist() == [0]
+
+
 # ------------------------------------------------------------------ greedy bond assembly
 def _assembly_case(rng, n_lo, n_hi):
     """A random fragment set: atoms, bonds inside the fragments, groups, candidates between
