@@ -31,6 +31,12 @@ __device__ unsigned long long psvae_exp_stamps[8 * 8192];
 extern "C" int psvae_exp_read_stamps(unsigned long long *host, int n) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(psvae_exp_stamps), sizeof(unsigned long long) * n);
 }
+// epilogue of wave 0: [0] bias rows ready, then per accumulator tile [1+2j] patch written and
+// waited for, [2+2j] its four stores issued
+__device__ unsigned long long psvae_exp_epi[12 * 8192];
+extern "C" int psvae_exp_read_epi(unsigned long long *host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(psvae_exp_epi), sizeof(unsigned long long) * n);
+}
 #endif
 
 namespace {
@@ -56,7 +62,7 @@ struct GemmArgs {
     int k_chunk;          // multiple of 32
     float *ws;            // [split_k][M][ws_ld] when split_k > 1
     int ws_ld;            // n_ext rounded up to a multiple of 4
-    int c_vec;            // C (and ws) rows may be written 16 bytes at a time
+    int c_vec;            // C (and ws) rows may be written 16 bytes at a time; 2: and byte offsets fit 32 bits
     int nt_m, nt_n, bn;   // tiles and column-tile width
     int wn;               // wave grid of the panel kernel: 1 = 4 x 1, 2 = 2 x 2
 };
@@ -318,6 +324,22 @@ __global__ __launch_bounds__(THREADS, (MASK || WN > 1 || TN > 5) ? 2 : 3) void g
             for (int j = 0; j < TN; ++j)
                 asm volatile("" : "+v"(bias4[j].x), "+v"(bias4[j].y), "+v"(bias4[j].z), "+v"(bias4[j].w));
         }
+        // Instructions of a wave that shares its SIMD with MFMA loops issue an order of magnitude
+        // slower than alone (stamps: 0.16 us for a tile's LDS transposition, 1.3-2 us for the ~160
+        // vector instructions around its four stores), so the common case - a tile that lies fully
+        // inside C - runs on row pointers computed once, immediate column offsets and no bounds tests.
+        const bool rows_full = g.c_vec == 2 && m0 + wave_m * 32 + 32 <= g.M;
+        unsigned ro[4];   // byte offsets of this lane's four rows (c_vec == 2: they fit 32 bits)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            ro[i] = rows_full ? (unsigned)(((long long)(m0 + wave_m * 32 + prow + 8 * i) * ld + n0 + wave_n * TN * 32 + pc4) * 4)
+                              : 0u;
+        char *out_b = reinterpret_cast<char *>(out);
+#ifdef PSVAE_EXP_CLOCK
+        unsigned long long exp_e[12];
+        for (int q = 0; q < 12; ++q) exp_e[q] = 0;
+        exp_e[0] = __builtin_amdgcn_s_memrealtime();
+#endif
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int cbase = n0 + (wave_n * TN + j) * 32;
@@ -325,6 +347,30 @@ __global__ __launch_bounds__(THREADS, (MASK || WN > 1 || TN > 5) ? 2 : 3) void g
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 patch[((r & 3) + 8 * (r >> 2) + 4 * lhi) * EPI_STRIDE + l31] = acc[j][r];
+            if (rows_full && !use_old && !use_gate && cbase + 32 <= g.N) {   // wave-uniform: the whole tile is inside C
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef PSVAE_EXP_CLOCK
+                if (j < 5) exp_e[1 + 2 * j] = __builtin_amdgcn_s_memrealtime();
+#endif
+                const float4 b4 = bias4[j];
+                const float inf = __builtin_inff();
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float4 v = *reinterpret_cast<const float4 *>(patch + (prow + 8 * i) * EPI_STRIDE + pc4);
+                    if (!split) {
+                        v.x += b4.x, v.y += b4.y, v.z += b4.z, v.w += b4.w;
+                        if (g.act == PSVAE_ACT_RELU)   // one v_med3_f32 per element
+                            v.x = __builtin_amdgcn_fmed3f(v.x, 0.f, inf), v.y = __builtin_amdgcn_fmed3f(v.y, 0.f, inf),
+                            v.z = __builtin_amdgcn_fmed3f(v.z, 0.f, inf), v.w = __builtin_amdgcn_fmed3f(v.w, 0.f, inf);
+                    }
+                    *reinterpret_cast<float4 *>(out_b + ro[i] + 128 * j) = v;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // patch is rewritten by the next tile
+#ifdef PSVAE_EXP_CLOCK
+                if (j < 5) exp_e[2 + 2 * j] = __builtin_amdgcn_s_memrealtime();
+#endif
+                continue;
+            }
             const int col = cbase + pc4;
             float4 old4[4], gate4[4];
             if (use_old || use_gate) {
@@ -344,6 +390,9 @@ __global__ __launch_bounds__(THREADS, (MASK || WN > 1 || TN > 5) ? 2 : 3) void g
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef PSVAE_EXP_CLOCK
+            if (j < 5) exp_e[1 + 2 * j] = __builtin_amdgcn_s_memrealtime();
+#endif
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = m0 + wave_m * 32 + prow + 8 * i;
@@ -375,7 +424,14 @@ __global__ __launch_bounds__(THREADS, (MASK || WN > 1 || TN > 5) ? 2 : 3) void g
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // patch is rewritten by the next tile
+#ifdef PSVAE_EXP_CLOCK
+            if (j < 5) exp_e[2 + 2 * j] = __builtin_amdgcn_s_memrealtime();
+#endif
         }
+#ifdef PSVAE_EXP_CLOCK
+        if (tid == 0 && blockIdx.x < 8192)
+            for (int q = 0; q < 11; ++q) psvae_exp_epi[12 * blockIdx.x + q] = exp_e[q];
+#endif
     } else {
         const int row0 = m0 + wave_m * 32 + 4 * lhi;
 #pragma unroll
@@ -627,6 +683,7 @@ extern "C" int psvae_gemm_f32(int M, int N, int K, const float *A, const float *
     g.ws_ld = (g.n_ext + 3) / 4 * 4;
     g.c_vec = (split_k > 1 ? psvae_aligned16(workspace) : (psvae_aligned16(C) && ldc % 4 == 0)) && N % 4 == 0 &&
               (bias == nullptr || psvae_aligned16(bias)) && (cmask == nullptr || psvae_aligned16(cmask));
+    if (g.c_vec && (long long)M * (split_k > 1 ? g.ws_ld : ldc) * 4 < (1ll << 32)) g.c_vec = 2;   // 32-bit byte offsets
     g.A = A, g.amask = amask, g.sa_m = sa_m, g.sa_k = sa_k;
     g.B = B, g.sb_k = sb_k, g.sb_n = sb_n;
     g.C = C, g.ldc = ldc, g.bias = bias, g.rowsum = rowsum, g.cmask = cmask, g.act = act;
