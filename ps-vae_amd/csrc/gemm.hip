@@ -151,7 +151,10 @@ struct TileLoader {
         }
     }
 
-    template <bool MASK, bool ONES>
+    // INTERIOR: the whole tile lies inside the operand (no bounds to apply, no ones column): the
+    // staging then costs its LDS writes only, which matters because vector instructions beside
+    // other waves' MFMA loops issue several times slower than alone.
+    template <bool MASK, bool ONES, bool INTERIOR = false>
     __device__ static __forceinline__ void store(float *T, const float4 (&r)[PER_THREAD],
                                                  const float4 (&rm)[MASK ? PER_THREAD : 1], int x0, int k0, int X,
                                                  int k_end, int ones_x, int tid) {
@@ -159,7 +162,7 @@ struct TileLoader {
         for (int i = 0; i < PER_THREAD; ++i) {
             const Coord c = coord(i, tid, x0, k0);
             if (!c.in_tile) continue;
-            const bool ok = c.x < X && c.k < k_end;
+            const bool ok = INTERIOR || (c.x < X && c.k < k_end);
             float4 v = r[i];
             if (MASK) {
                 const float4 m = rm[i];
@@ -167,7 +170,7 @@ struct TileLoader {
                 v.z = m.z > 0.f ? v.z : 0.f, v.w = m.w > 0.f ? v.w : 0.f;
             }
             v.x = ok ? v.x : 0.f, v.y = ok ? v.y : 0.f, v.z = ok ? v.z : 0.f, v.w = ok ? v.w : 0.f;
-            if (ONES && !KCONTIG) v.x = (c.k < k_end && c.x == ones_x) ? 1.f : v.x;
+            if (ONES && !KCONTIG && !INTERIOR) v.x = (c.k < k_end && c.x == ones_x) ? 1.f : v.x;
             const int item = tid + THREADS * i;
             if (KCONTIG) {
                 const int kq = item % (BK / 4), x = item / (BK / 4);
@@ -222,6 +225,8 @@ __global__ __launch_bounds__(THREADS, (MASK || WN > 1 || TN > 5) ? 2 : 3) void g
         LA::template load<MASK>(ra, rma, g.A, g.amask, g.sa_m, g.sa_k, m0, k_begin, g.M, k_end, tid);
         LB::template load<false>(rb, rmb, g.B, nullptr, g.sb_n, g.sb_k, n0, k_begin, n_lim, k_end, tid);
     }
+    // operand tiles without an edge in x (rows of A / columns of B incl. the ones column)
+    const bool a_inside = m0 + BM <= g.M, b_inside = n0 + BN <= n_lim;
     const float *a_rd = As + lhi * LA::STRIDE + wave_m * 32 + l31;
     const float *b_rd = Bs + lhi * LB::STRIDE + wave_n * TN * 32 + l31;
 #ifdef PSVAE_EXP_CLOCK
@@ -231,8 +236,14 @@ __global__ __launch_bounds__(THREADS, (MASK || WN > 1 || TN > 5) ? 2 : 3) void g
 #ifdef PSVAE_EXP_NOSTORE   // timing experiment only: wrong results
         if (k0 == k_begin) {
 #endif
-        LA::template store<MASK, false>(As, ra, rma, m0, k0, g.M, k_end, -1, tid);
-        LB::template store<false, ONES>(Bs, rb, rmb, n0, k0, n_lim, k_end, ones_x, tid);
+        if (k0 + BK <= k_end && a_inside)   // wave-uniform
+            LA::template store<MASK, false, true>(As, ra, rma, m0, k0, g.M, k_end, -1, tid);
+        else
+            LA::template store<MASK, false>(As, ra, rma, m0, k0, g.M, k_end, -1, tid);
+        if (k0 + BK <= k_end && b_inside)
+            LB::template store<false, ONES, true>(Bs, rb, rmb, n0, k0, n_lim, k_end, ones_x, tid);
+        else
+            LB::template store<false, ONES>(Bs, rb, rmb, n0, k0, n_lim, k_end, ones_x, tid);
         __syncthreads();
 #ifdef PSVAE_EXP_CLOCK
         if (k0 == k_begin) exp_r_first = __builtin_amdgcn_s_memrealtime();
