@@ -20,24 +20,10 @@
 // lane (lanes 0-31 read consecutive x at k, lanes 32-63 at k+1 — the 32x32x2 operand layout).
 // Row strides are chosen per loader so the staging stores are conflict-free too.
 // Workgroups that share an A row-panel sit on one XCD (blockIdx % 8).
-#include <stdlib.h>
-
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#ifdef PSVAE_EXP_CLOCK   // diagnostic build only: cycle / wall-clock stamps around the k loop
-__device__ unsigned long long psvae_exp_stamps[8 * 8192];
-extern "C" int psvae_exp_read_stamps(unsigned long long *host, int n) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(psvae_exp_stamps), sizeof(unsigned long long) * n);
-}
-// epilogue of wave 0: [0] bias rows ready, then per accumulator tile [1+2j] patch written and
-// waited for, [2+2j] its four stores issued
-__device__ unsigned long long psvae_exp_epi[12 * 8192];
-extern "C" int psvae_exp_read_epi(unsigned long long *host, int n) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(psvae_exp_epi), sizeof(unsigned long long) * n);
-}
-#endif
 
 namespace {
 
@@ -197,10 +183,6 @@ __global__ __launch_bounds__(THREADS, (MASK || WN > 1 || TN > 5) ? 2 : 3) void g
     __shared__ __align__(16) float smem[LDS_FLOATS];
     float *As = smem, *Bs = smem + A_FLOATS;
 
-#ifdef PSVAE_EXP_CLOCK
-    const unsigned long long exp_r_entry = __builtin_amdgcn_s_memrealtime();
-    unsigned long long exp_r_first = 0;
-#endif
     int tile_m, tile_n, z;
     if (!tile_of_block(g, tile_m, tile_n, z)) return;
     const int m0 = tile_m * BM, n0 = tile_n * g.bn;
@@ -229,13 +211,7 @@ __global__ __launch_bounds__(THREADS, (MASK || WN > 1 || TN > 5) ? 2 : 3) void g
     const bool a_inside = m0 + BM <= g.M, b_inside = n0 + BN <= n_lim;
     const float *a_rd = As + lhi * LA::STRIDE + wave_m * 32 + l31;
     const float *b_rd = Bs + lhi * LB::STRIDE + wave_n * TN * 32 + l31;
-#ifdef PSVAE_EXP_CLOCK
-    const unsigned long long exp_t0 = __builtin_amdgcn_s_memtime(), exp_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
     for (int k0 = k_begin; k0 < k_end; k0 += BK) {
-#ifdef PSVAE_EXP_NOSTORE   // timing experiment only: wrong results
-        if (k0 == k_begin) {
-#endif
         if (k0 + BK <= k_end && a_inside)   // wave-uniform
             LA::template store<MASK, false, true>(As, ra, rma, m0, k0, g.M, k_end, -1, tid);
         else
@@ -245,17 +221,7 @@ __global__ __launch_bounds__(THREADS, (MASK || WN > 1 || TN > 5) ? 2 : 3) void g
         else
             LB::template store<false, ONES>(Bs, rb, rmb, n0, k0, n_lim, k_end, ones_x, tid);
         __syncthreads();
-#ifdef PSVAE_EXP_CLOCK
-        if (k0 == k_begin) exp_r_first = __builtin_amdgcn_s_memrealtime();
-#endif
-#ifdef PSVAE_EXP_NOSTORE
-        }
-#endif
-#ifdef PSVAE_EXP_NOLOAD
-        if (false) {
-#else
         if (k0 + BK < k_end) {
-#endif
             LA::template load<MASK>(ra, rma, g.A, g.amask, g.sa_m, g.sa_k, m0, k0 + BK, g.M, k_end, tid);
             LB::template load<false>(rb, rmb, g.B, nullptr, g.sb_n, g.sb_k, n0, k0 + BK, n_lim, k_end, tid);
         }
@@ -267,20 +233,12 @@ __global__ __launch_bounds__(THREADS, (MASK || WN > 1 || TN > 5) ? 2 : 3) void g
         const int k_live = k_end - k0;   // the last k-tile of a chunk may be partly empty
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-#ifndef PSVAE_EXP_NOBREAK
             if (kk > 0 && kk >= k_live) break;   // wave-uniform
-#endif
             float a_nxt = 0.f, b_nxt[TN];
             if (kk + 2 < BK) {
-#ifdef PSVAE_EXP_NOLDSREAD   // timing experiment only: wrong results
-                a_nxt = a_cur;
-#pragma unroll
-                for (int j = 0; j < TN; ++j) b_nxt[j] = b_cur[j];
-#else
                 a_nxt = a_rd[(kk + 2) * LA::STRIDE];
 #pragma unroll
                 for (int j = 0; j < TN; ++j) b_nxt[j] = b_rd[(kk + 2) * LB::STRIDE + j * 32];
-#endif
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -296,14 +254,9 @@ __global__ __launch_bounds__(THREADS, (MASK || WN > 1 || TN > 5) ? 2 : 3) void g
                 for (int j = 0; j < TN; ++j) b_cur[j] = b_nxt[j];
             }
         }
-#ifndef PSVAE_EXP_NOSTORE
         __syncthreads();
-#endif
     }
 
-#ifdef PSVAE_EXP_CLOCK
-    const unsigned long long exp_t1 = __builtin_amdgcn_s_memtime(), exp_r1 = __builtin_amdgcn_s_memrealtime();
-#endif
     // Epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) +
     // 4 * (lane >> 5): a direct store would be 16 dword stores per tile, each touching two
     // 128-B row segments.  Instead every wave transposes one tile at a time through its own
@@ -346,11 +299,6 @@ __global__ __launch_bounds__(THREADS, (MASK || WN > 1 || TN > 5) ? 2 : 3) void g
             ro[i] = rows_full ? (unsigned)(((long long)(m0 + wave_m * 32 + prow + 8 * i) * ld + n0 + wave_n * TN * 32 + pc4) * 4)
                               : 0u;
         char *out_b = reinterpret_cast<char *>(out);
-#ifdef PSVAE_EXP_CLOCK
-        unsigned long long exp_e[12];
-        for (int q = 0; q < 12; ++q) exp_e[q] = 0;
-        exp_e[0] = __builtin_amdgcn_s_memrealtime();
-#endif
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int cbase = n0 + (wave_n * TN + j) * 32;
@@ -360,9 +308,6 @@ __global__ __launch_bounds__(THREADS, (MASK || WN > 1 || TN > 5) ? 2 : 3) void g
                 patch[((r & 3) + 8 * (r >> 2) + 4 * lhi) * EPI_STRIDE + l31] = acc[j][r];
             if (rows_full && !use_old && !use_gate && cbase + 32 <= g.N) {   // wave-uniform: the whole tile is inside C
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#ifdef PSVAE_EXP_CLOCK
-                if (j < 5) exp_e[1 + 2 * j] = __builtin_amdgcn_s_memrealtime();
-#endif
                 const float4 b4 = bias4[j];
                 const float inf = __builtin_inff();
 #pragma unroll
@@ -377,9 +322,6 @@ __global__ __launch_bounds__(THREADS, (MASK || WN > 1 || TN > 5) ? 2 : 3) void g
                     *reinterpret_cast<float4 *>(out_b + ro[i] + 128 * j) = v;
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // patch is rewritten by the next tile
-#ifdef PSVAE_EXP_CLOCK
-                if (j < 5) exp_e[2 + 2 * j] = __builtin_amdgcn_s_memrealtime();
-#endif
                 continue;
             }
             const int col = cbase + pc4;
@@ -401,16 +343,10 @@ __global__ __launch_bounds__(THREADS, (MASK || WN > 1 || TN > 5) ? 2 : 3) void g
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#ifdef PSVAE_EXP_CLOCK
-            if (j < 5) exp_e[1 + 2 * j] = __builtin_amdgcn_s_memrealtime();
-#endif
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = m0 + wave_m * 32 + prow + 8 * i;
                 float4 v = *reinterpret_cast<const float4 *>(patch + (prow + 8 * i) * EPI_STRIDE + pc4);
-#ifdef PSVAE_EXP_NOEPI   // timing experiment only
-                if (v.x != 12345.678f) continue;
-#endif
                 if (row >= g.M || col >= col_lim) continue;
                 if (split) {
                     *reinterpret_cast<float4 *>(out + (long long)row * ld + col) = v;
@@ -435,14 +371,7 @@ __global__ __launch_bounds__(THREADS, (MASK || WN > 1 || TN > 5) ? 2 : 3) void g
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // patch is rewritten by the next tile
-#ifdef PSVAE_EXP_CLOCK
-            if (j < 5) exp_e[2 + 2 * j] = __builtin_amdgcn_s_memrealtime();
-#endif
         }
-#ifdef PSVAE_EXP_CLOCK
-        if (tid == 0 && blockIdx.x < 8192)
-            for (int q = 0; q < 11; ++q) psvae_exp_epi[12 * blockIdx.x + q] = exp_e[q];
-#endif
     } else {
         const int row0 = m0 + wave_m * 32 + 4 * lhi;
 #pragma unroll
@@ -455,17 +384,6 @@ __global__ __launch_bounds__(THREADS, (MASK || WN > 1 || TN > 5) ? 2 : 3) void g
             }
         }
     }
-#ifdef PSVAE_EXP_CLOCK
-    if (tid == 0 && blockIdx.x < 8192) {
-        const unsigned long long r2 = __builtin_amdgcn_s_memrealtime();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned long long r3 = __builtin_amdgcn_s_memrealtime();
-        unsigned long long *d = psvae_exp_stamps + 8 * blockIdx.x;
-        d[0] = exp_r_entry, d[1] = exp_r0, d[2] = exp_r_first, d[3] = exp_r1, d[4] = r2, d[5] = r3;
-        d[6] = exp_t1 - exp_t0;
-        d[7] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);
-    }
-#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -568,25 +486,19 @@ __global__ void gemm_splitk_reduce_kernel(GemmArgs g) {
     }
 }
 
-// diagnostic knob: extra dynamic LDS per workgroup lowers the number of resident workgroups
-static size_t exp_dyn_lds() {
-    static const size_t v = [] {
-        const char *e = getenv("PSVAE_GEMM_PAD_LDS");
-        return e ? (size_t)atoi(e) : (size_t)0;
-    }();
-    return v;
-}
-
 template <int TN, int BK>
 void launch_panel(const GemmArgs &g, bool a_kc, bool b_kc, dim3 grid, hipStream_t s) {
     const bool mask = g.amask != nullptr, ones = g.rowsum != nullptr;
     const dim3 blk(THREADS);
 #define PSVAE_PANEL(AKC, BKC, MASK, ONES) \
-    hipLaunchKernelGGL((gemm_panel_kernel<TN, BK, AKC, BKC, MASK, ONES>), grid, blk, exp_dyn_lds(), s, g)
+    hipLaunchKernelGGL((gemm_panel_kernel<TN, BK, AKC, BKC, MASK, ONES>), grid, blk, 0, s, g)
     if (a_kc && b_kc) {                 // forward X W^T
         if (mask) PSVAE_PANEL(true, true, true, false); else PSVAE_PANEL(true, true, false, false);
-    } else if (a_kc) {                  // input gradient dY W
-        if (mask) PSVAE_PANEL(true, false, true, false); else PSVAE_PANEL(true, false, false, false);
+    } else if (a_kc) {                  // input gradient dY W (rowsum: the ones column of the n-contiguous B)
+        if (mask && ones) PSVAE_PANEL(true, false, true, true);
+        else if (mask) PSVAE_PANEL(true, false, true, false);
+        else if (ones) PSVAE_PANEL(true, false, false, true);
+        else PSVAE_PANEL(true, false, false, false);
     } else if (b_kc) {
         if (mask) PSVAE_PANEL(false, true, true, false); else PSVAE_PANEL(false, true, false, false);
     } else if (g.wn == 2) {             // the same on the 2 x 2 wave grid (TN == 5 only)
@@ -608,17 +520,10 @@ void launch_panel(const GemmArgs &g, bool a_kc, bool b_kc, dim3 grid, hipStream_
 #undef PSVAE_PANEL
 }
 
-// Widest column tile (a multiple of 32, at most 352 = 11 accumulator tiles per wave).
-// PSVAE_GEMM_MAX_BN overrides it for tuning runs.
-int panel_max_bn() {
-    static int v = 0;
-    if (v == 0) {
-        const char *e = getenv("PSVAE_GEMM_MAX_BN");
-        int x = e ? atoi(e) : 224;
-        v = x < 32 ? 32 : (x > 352 ? 352 : x / 32 * 32);
-    }
-    return v;
-}
+// Widest column tile: 224 columns = 7 accumulator tiles per wave (wider tiles were measured
+// slower: they leave two workgroups per CU).
+constexpr int PANEL_MAX_BN = 224;
+int panel_max_bn() { return PANEL_MAX_BN; }
 
 // Column tiling of the panel kernel: nc tiles of width bn (a multiple of 32), and the
 // instantiated TN that covers bn.

@@ -86,6 +86,25 @@ def test_gemm_strided_output_and_operands():
     close(out, want, what='strided slot')
 
 
+@pytest.mark.parametrize('M,N,K', [(1000, 300, 328), (64, 96, 40), (31, 8, 12)])
+def test_gemm_rowsum_with_row_major_operands(M, N, K):
+    """rowsum = sum_k A(m,k) with A [M,K] row-major (k-contiguous) and B [K,N] row-major
+    (n-contiguous): the input-gradient form of the panel kernel, and the small generic one."""
+    from ps_vae_amd import hip
+    d = dev()
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randn(M, K, generator=g)
+    b = torch.randn(K, N, generator=g)
+    ad, bd = a.to(d), b.to(d)
+    for accumulate in (False, True):
+        c = torch.full((M, N), 0.5, device=d)
+        rs = torch.full((M,), -1.0, device=d)
+        hip.gemm(M, N, K, ad, K, 1, bd, N, 1, c, N, rowsum=rs, accumulate=accumulate, split_k=1)
+        base = 1.0 if accumulate else 0.0
+        close(c, base * 0.5 + a.double() @ b.double(), what='C')
+        close(rs, base * -1.0 + a.double().sum(1), what='rowsum')
+
+
 def test_gemm_large_split_k():
     from ps_vae_amd import hip
     d = dev()
