@@ -148,6 +148,22 @@ int psvae_gine_aggregate_bwd(int V, int H, int C, const float *x, int ldx, const
                              const float *add, int ldadd, float *g_x, int ldgx, float *g_table,
                              int accumulate_table, void *workspace, size_t workspace_bytes, void *stream);
 
+/* psvae_gine_aggregate_bwd for callers that cannot allocate.  It has no counterpart in the
+ * reference; it exists for code under HIP graph capture, tight serving loops and harnesses that
+ * forbid hipMalloc.  Same arguments and results as psvae_gine_aggregate_bwd, without the
+ * workspace: the table-gradient partials go to a fixed device array inside the library
+ * (1024 x PSVAE_NOALLOC_MAX_CH floats = 8 MiB, held by every GPU the library runs on until the
+ * process ends).  C * H > PSVAE_NOALLOC_MAX_CH is rejected with PSVAE_ETOOLARGE; V is not
+ * limited.  It calls no hipMalloc / hipFree.  The first call on a device looks the array's
+ * address up (make that call — V = 0 is enough — outside graph capture).  All calls on one GPU
+ * share the array: calls that overlap on one GPU (two streams or two threads) race. */
+#define PSVAE_NOALLOC_MAX_CH 2048
+int psvae_gine_aggregate_bwd_noalloc(int V, int H, int C, const float *x, int ldx, const float *table,
+                                     const float *g, int ldg,
+                                     const int32_t *t_row_ptr, const int32_t *t_col, const uint8_t *t_cls,
+                                     const float *add, int ldadd, float *g_x, int ldgx, float *g_table,
+                                     int accumulate_table, void *stream);
+
 /* ------------------------------------------------------------------------------------
  * f32 matrix product on the matrix cores (v_mfma_f32_32x32x2_f32: exact f32 FMA chains):
  *     C[m][n] (+)= act( sum_k A(m,k) * B(k,n) + bias[n] )

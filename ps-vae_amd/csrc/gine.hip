@@ -13,7 +13,7 @@
 // node range.  Each wave therefore reads whole contiguous row segments (16 B per lane).
 // Molecules are small and contiguous in node order, so the neighbour rows a block gathers
 // are the rows it (or the adjacent block) streams anyway: they are served by L1/L2.
-#include <stdlib.h>
+#include <mutex>
 
 #include "common.h"
 
@@ -207,15 +207,9 @@ Shape shape_for(int V, int H, int max_blocks) {
 }
 
 // Most workgroups the backward is cut into (each writes one [C,H] slab of table-gradient
-// partials).  PSVAE_GINE_BWD_BLOCKS overrides it for tuning runs.
-int bwd_max_blocks() {
-    static const int v = [] {
-        const char *e = getenv("PSVAE_GINE_BWD_BLOCKS");
-        const int x = e ? atoi(e) : 1024;
-        return x < 1 ? 1 : x;
-    }();
-    return v;
-}
+// partials; more workgroups were measured slower: the slab reduction grows with them).
+constexpr int BWD_MAX_BLOCKS = 1024;
+int bwd_max_blocks() { return BWD_MAX_BLOCKS; }
 
 int check_common(const char *fn, int V, int H, int C, const void *x, int ldx) {
     PSVAE_REQUIRE(V >= 0 && H > 0 && C > 0, PSVAE_EINVAL, "%s: bad sizes V=%d H=%d C=%d", fn, V, H, C);
@@ -251,45 +245,107 @@ extern "C" size_t psvae_gine_aggregate_bwd_workspace_bytes(int V, int H, int C) 
     return (size_t)s.blocks * C * H * sizeof(float);
 }
 
+// Checks + launches shared by the two backward entry points; `partial` holds one [C,H] slab of
+// table-gradient partials per workgroup (at least workspace_bytes(V, H, C) bytes).
+static int aggregate_bwd_impl(const char *fn, int V, int H, int C, const float *x, int ldx, const float *table,
+                              const float *g, int ldg, const int32_t *t_row_ptr, const int32_t *t_col,
+                              const uint8_t *t_cls, const float *add, int ldadd, float *g_x, int ldgx,
+                              float *g_table, int accumulate_table, float *partial, hipStream_t s_) {
+    if (V == 0) return accumulate_table ? PSVAE_OK : (int)hipMemsetAsync(g_table, 0, (size_t)C * H * sizeof(float), s_);
+    PSVAE_REQUIRE(add == nullptr || (psvae_aligned16(add) && ldadd % 4 == 0 && ldadd >= H), PSVAE_EINVAL,
+                  "%s: bad `add` operand", fn);
+    PSVAE_REQUIRE(table && t_row_ptr && g && g_x && psvae_aligned16(table) && psvae_aligned16(g) &&
+                      psvae_aligned16(g_x), PSVAE_EINVAL, "%s: null or misaligned operand", fn);
+    PSVAE_REQUIRE(ldg % 4 == 0 && ldg >= H && ldgx % 4 == 0 && ldgx >= H, PSVAE_EINVAL, "%s: bad row stride", fn);
+    const Shape s = shape_for(V, H, bwd_max_blocks());
+    const size_t lds = (size_t)s.slots * C * s.cols * sizeof(float4);
+    PSVAE_REQUIRE(lds <= 64 * 1024, PSVAE_ETOOLARGE, "%s: LDS need %zu", fn, lds);
+#define PSVAE_AGG_BWD(MAXC)                                                                                          \
+    hipLaunchKernelGGL(gine_aggregate_bwd_kernel<MAXC>, dim3(s.blocks), dim3(s.threads), lds, s_, V, C, s.cols,       \
+                       s.slots, s.nodes_per_block, (const float4 *)x, ldx / 4, (const float4 *)table,                \
+                       (const float4 *)g, ldg / 4, t_row_ptr, t_col, t_cls, (const float4 *)add, ldadd / 4,          \
+                       (float4 *)g_x, ldgx / 4, (float4 *)partial)
+    if (C <= 4) PSVAE_AGG_BWD(4); else PSVAE_AGG_BWD(8);
+#undef PSVAE_AGG_BWD
+    PSVAE_CHECK_LAUNCH(fn);
+    const int n_out = C * H;
+    hipLaunchKernelGGL(gine_table_reduce_kernel, dim3(psvae_cdiv(n_out, 32)), dim3(32 * REDUCE_GROUPS), 0, s_, n_out,
+                       s.blocks, (const float *)partial, g_table, accumulate_table);
+    PSVAE_CHECK_LAUNCH(fn);
+    return PSVAE_OK;
+}
+
 extern "C" int psvae_gine_aggregate_bwd(int V, int H, int C, const float *x, int ldx, const float *table,
                                         const float *g, int ldg, const int32_t *t_row_ptr,
                                         const int32_t *t_col, const uint8_t *t_cls, const float *add, int ldadd,
                                         float *g_x, int ldgx, float *g_table, int accumulate_table,
                                         void *workspace, size_t workspace_bytes, void *stream) {
-    int rc = check_common("psvae_gine_aggregate_bwd", V, H, C, x, ldx);
+    const char *fn = "psvae_gine_aggregate_bwd";
+    int rc = check_common(fn, V, H, C, x, ldx);
     if (rc) return rc;
-    PSVAE_REQUIRE(C <= 8, PSVAE_ETOOLARGE, "psvae_gine_aggregate_bwd: at most 8 edge classes (C=%d)", C);
-    PSVAE_REQUIRE(g_table != nullptr, PSVAE_EINVAL, "psvae_gine_aggregate_bwd: g_table is null");
-    hipStream_t s_ = (hipStream_t)stream;
-    if (V == 0) return accumulate_table ? PSVAE_OK : (int)hipMemsetAsync(g_table, 0, (size_t)C * H * sizeof(float), s_);
-    PSVAE_REQUIRE(add == nullptr || (psvae_aligned16(add) && ldadd % 4 == 0 && ldadd >= H), PSVAE_EINVAL,
-                  "psvae_gine_aggregate_bwd: bad `add` operand");
-    PSVAE_REQUIRE(table && t_row_ptr && g && g_x && psvae_aligned16(table) && psvae_aligned16(g) &&
-                      psvae_aligned16(g_x), PSVAE_EINVAL, "psvae_gine_aggregate_bwd: null or misaligned operand");
-    PSVAE_REQUIRE(ldg % 4 == 0 && ldg >= H && ldgx % 4 == 0 && ldgx >= H, PSVAE_EINVAL,
-                  "psvae_gine_aggregate_bwd: bad row stride");
-    PSVAE_REQUIRE(workspace && psvae_aligned16(workspace) &&
-                      workspace_bytes >= psvae_gine_aggregate_bwd_workspace_bytes(V, H, C),
-                  PSVAE_EWORKSPACE, "psvae_gine_aggregate_bwd: workspace too small");
-    const Shape s = shape_for(V, H, bwd_max_blocks());
-    const size_t lds = (size_t)s.slots * C * s.cols * sizeof(float4);
-    PSVAE_REQUIRE(lds <= 64 * 1024, PSVAE_ETOOLARGE, "psvae_gine_aggregate_bwd: LDS need %zu", lds);
-    if (C <= 4)
-        hipLaunchKernelGGL(gine_aggregate_bwd_kernel<4>, dim3(s.blocks), dim3(s.threads), lds, s_, V, C, s.cols,
-                           s.slots, s.nodes_per_block, (const float4 *)x, ldx / 4, (const float4 *)table,
-                           (const float4 *)g, ldg / 4, t_row_ptr, t_col, t_cls, (const float4 *)add, ldadd / 4, (float4 *)g_x,
-                           ldgx / 4,
-                           (float4 *)workspace);
-    else
-        hipLaunchKernelGGL(gine_aggregate_bwd_kernel<8>, dim3(s.blocks), dim3(s.threads), lds, s_, V, C, s.cols,
-                           s.slots, s.nodes_per_block, (const float4 *)x, ldx / 4, (const float4 *)table,
-                           (const float4 *)g, ldg / 4, t_row_ptr, t_col, t_cls, (const float4 *)add, ldadd / 4, (float4 *)g_x,
-                           ldgx / 4,
-                           (float4 *)workspace);
-    PSVAE_CHECK_LAUNCH("psvae_gine_aggregate_bwd");
-    const int n_out = C * H;
-    hipLaunchKernelGGL(gine_table_reduce_kernel, dim3(psvae_cdiv(n_out, 32)), dim3(32 * REDUCE_GROUPS), 0, s_, n_out, s.blocks,
-                       (const float *)workspace, g_table, accumulate_table);
-    PSVAE_CHECK_LAUNCH("psvae_gine_aggregate_bwd (table reduce)");
+    PSVAE_REQUIRE(C <= 8, PSVAE_ETOOLARGE, "%s: at most 8 edge classes (C=%d)", fn, C);
+    PSVAE_REQUIRE(g_table != nullptr, PSVAE_EINVAL, "%s: g_table is null", fn);
+    PSVAE_REQUIRE(V == 0 || (workspace && psvae_aligned16(workspace) &&
+                             workspace_bytes >= psvae_gine_aggregate_bwd_workspace_bytes(V, H, C)),
+                  PSVAE_EWORKSPACE, "%s: workspace too small", fn);
+    return aggregate_bwd_impl(fn, V, H, C, x, ldx, table, g, ldg, t_row_ptr, t_col, t_cls, add, ldadd, g_x, ldgx,
+                              g_table, accumulate_table, (float *)workspace, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// The same backward for callers that cannot allocate (HIP graph capture, serving loops that
+// forbid hipMalloc): the table-gradient partials go to a fixed device array of this library
+// instead of a caller workspace.  Every GPU holds its own copy of the array at its own address,
+// looked up once per device; all calls on one GPU share it, so calls that overlap on one GPU
+// (two streams, two threads) race.  Nothing in it has to start at zero: the kernel writes every
+// slab the reduction reads.
+// ------------------------------------------------------------------------------------------
+static __device__ __align__(256) float scratch[(size_t)BWD_MAX_BLOCKS * PSVAE_NOALLOC_MAX_CH];
+
+namespace {
+constexpr int MAX_DEVICES = 64;
+float *g_scratch_ptr[MAX_DEVICES];   // device address of `scratch` on each GPU (null: not looked up yet)
+std::mutex g_scratch_mu;
+
+int scratch_of_current_device(const char *fn, float **out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) {
+        psvae_set_error("%s: hipGetDevice: %s", fn, hipGetErrorString(e));
+        return (int)e;
+    }
+    PSVAE_REQUIRE(dev >= 0 && dev < MAX_DEVICES, PSVAE_ETOOLARGE, "%s: device index %d beyond %d", fn, dev, MAX_DEVICES);
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (g_scratch_ptr[dev] == nullptr) {
+        float *p = nullptr;
+        e = hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || p == nullptr) {
+            psvae_set_error("%s: hipGetSymbolAddress(scratch) on device %d: %s", fn, dev, hipGetErrorString(e));
+            return e != hipSuccess ? (int)e : (int)hipErrorInvalidSymbol;
+        }
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
     return PSVAE_OK;
+}
+}  // namespace
+
+extern "C" int psvae_gine_aggregate_bwd_noalloc(int V, int H, int C, const float *x, int ldx, const float *table,
+                                                const float *g, int ldg, const int32_t *t_row_ptr,
+                                                const int32_t *t_col, const uint8_t *t_cls, const float *add,
+                                                int ldadd, float *g_x, int ldgx, float *g_table,
+                                                int accumulate_table, void *stream) {
+    const char *fn = "psvae_gine_aggregate_bwd_noalloc";
+    int rc = check_common(fn, V, H, C, x, ldx);
+    if (rc) return rc;
+    PSVAE_REQUIRE(C <= 8, PSVAE_ETOOLARGE, "%s: at most 8 edge classes (C=%d)", fn, C);
+    PSVAE_REQUIRE((long long)C * H <= PSVAE_NOALLOC_MAX_CH, PSVAE_ETOOLARGE,
+                  "%s: C*H = %lld exceeds the fixed scratch (PSVAE_NOALLOC_MAX_CH = %d floats per workgroup)", fn,
+                  (long long)C * H, PSVAE_NOALLOC_MAX_CH);
+    PSVAE_REQUIRE(g_table != nullptr, PSVAE_EINVAL, "%s: g_table is null", fn);
+    float *partial = nullptr;
+    rc = scratch_of_current_device(fn, &partial);   // also on V == 0: a set-up call outside graph capture
+    if (rc) return rc;
+    return aggregate_bwd_impl(fn, V, H, C, x, ldx, table, g, ldg, t_row_ptr, t_col, t_cls, add, ldadd, g_x, ldgx,
+                              g_table, accumulate_table, partial, (hipStream_t)stream);
 }

@@ -32,6 +32,8 @@ _SIGNATURES = {
     'psvae_gine_aggregate_bwd_workspace_bytes': (_c_size, [_c_int, _c_int, _c_int]),
     'psvae_gine_aggregate_bwd': (_c_int, [_c_int, _c_int, _c_int, _p, _c_int, _p, _p, _c_int, _p, _p, _p, _p,
                                           _c_int, _p, _c_int, _p, _c_int, _p, _c_size, _p]),
+    'psvae_gine_aggregate_bwd_noalloc': (_c_int, [_c_int, _c_int, _c_int, _p, _c_int, _p, _p, _c_int, _p, _p, _p, _p,
+                                                  _c_int, _p, _c_int, _p, _c_int, _p]),
     'psvae_gemm_f32_workspace_bytes': (_c_size, [_c_int, _c_int, _c_int, _c_int]),
     'psvae_gemm_f32': (_c_int, [_c_int, _c_int, _c_int, _p, _p, _c_i64, _c_i64, _p, _c_i64, _c_i64, _p, _c_i64,
                                 _p, _p, _p, _c_int, _c_int, _c_int, _p, _c_size, _p]),
@@ -295,6 +297,21 @@ def gine_aggregate_bwd(x, table, g, t_row_ptr, t_col, t_cls, g_x, g_table, add=N
                                         ptr(g_table, torch.float32), 1 if accumulate_table else 0,
                                         ptr(ws), nbytes, _stream())
     _check(rc, 'psvae_gine_aggregate_bwd')
+
+
+def gine_aggregate_bwd_noalloc(x, table, g, t_row_ptr, t_col, t_cls, g_x, g_table, add=None, accumulate_table=False):
+    """gine_aggregate_bwd through the entry point that allocates nothing (fixed scratch inside
+    the library; calls on one GPU must not overlap)."""
+    V, H = x.shape
+    px, ldx = _rows(x)
+    pg, ldg = _rows(g)
+    pgx, ldgx = _rows(g_x)
+    padd, ldadd = _rows(add) if add is not None else (None, H)
+    rc = lib().psvae_gine_aggregate_bwd_noalloc(V, H, table.shape[0], px, ldx, ptr(table, torch.float32), pg, ldg,
+                                                ptr(t_row_ptr, torch.int32), ptr(t_col, torch.int32),
+                                                ptr(t_cls, torch.uint8), padd, ldadd, pgx, ldgx,
+                                                ptr(g_table, torch.float32), 1 if accumulate_table else 0, _stream())
+    _check(rc, 'psvae_gine_aggregate_bwd_noalloc')
 
 
 def embed_atom_fwd(x, xp, xq, ea, ep, eq, out):
