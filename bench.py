@@ -126,7 +126,6 @@ def main():
 
     import ps_vae_amd  # noqa: F401
     from ps_vae_amd import hip
-    from ps_vae_amd.dist import FlatGradSync
     from ps_vae_amd.pl_models import PSVAEModel
     from ps_vae_amd.utils.nn_utils import build_config, default_args
     from ps_vae_amd.utils.tokenizer import Tokenizer
@@ -135,8 +134,8 @@ def main():
     cfg_args = default_args()
     torch.manual_seed(2021)                       # identical initial weights on every rank
     model = PSVAEModel(build_config(cfg_args, tok), tok).to(dev)
-    sync = FlatGradSync(model.parameters())
-    opt = torch.optim.Adam(model.parameters(), lr=cfg_args.lr, fused=True)
+    (opt,), _ = model.configure_optimizers()      # optim.FlatAdam: all-reduce + clip + Adam on flat buffers
+    opt.max_norm = cfg_args.grad_clip
     B = args.batch
     dataset = make_dataset(args.dataset or 4 * B, 2021 + rank, tok, dev)
     rng = np.random.default_rng(2021 + rank)
@@ -145,11 +144,9 @@ def main():
     def step():
         ids = rng.choice(len(dataset), size=B, replace=False)
         batch = dataset.collate_ids(ids)
-        sync.zero_grad()
+        opt.zero_grad()
         loss = model.training_step(batch, 0)
         loss.backward()
-        sync.sync()
-        sync.clip_grad_norm_(cfg_args.grad_clip)
         opt.step()
         model.global_step += 1
         return batch

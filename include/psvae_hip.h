@@ -323,6 +323,22 @@ int psvae_assemble_links(int B, int V, const int32_t *node_off, const int32_t *a
                          int sulfur_idx, uint8_t *accepted, int32_t *block, uint8_t *keep_atom,
                          int32_t *status, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ------------------------------------------------------------------------------------
+ * Optimiser tail on flat buffers of n floats (all parameters / gradients / Adam moments of the
+ * model laid out back to back): g *= grad_scale (1 / world size after the gradient all-reduce),
+ * global-norm clipping as torch.nn.utils.clip_grad_norm_ (Trainer gradient_clip_val,
+ * src/train.py:47; max_norm <= 0 disables it) and one torch.optim.Adam step
+ * (src/pl_models/ps_vae_model.py:123-127; step counts from 1, weight_decay is Adam's L2 form).
+ * write_grad != 0 leaves the scaled and clipped gradient in g, as clip_grad_norm_ does.
+ * norm_out (optional, device) receives the global gradient norm before clipping.
+ * Deterministic: fixed-order reductions, no atomics.  Buffers 16-byte aligned.
+ * ---------------------------------------------------------------------------------- */
+size_t psvae_clip_adam_workspace_bytes(long long n);
+int psvae_clip_adam_step(long long n, float *p, float *g, float *m, float *v, float grad_scale,
+                         float max_norm, double lr, double beta1, double beta2, double eps,
+                         double weight_decay, int step, int write_grad, float *norm_out,
+                         void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,14 +11,17 @@ import numpy as np
 import torch
 
 from .collate import collate_packed
-from .packed import PackedMolecules
+from .packed import PackedMolecules, load_step1_pickle
 
 
 class BPEMolDataset(torch.utils.data.Dataset):
     def __init__(self, fname, tokenizer, device='cuda', data=None):
-        """fname: a packed .npz (PackedMolecules.save) or a torch-saved list of process_step1
-        dicts ('processed_data.pkl' in the reference, :23-26, loaded with weights_only=True);
-        `data` passes the list directly."""
+        """fname: a packed .npz (PackedMolecules.save), or — as in the reference, :18-26 — the
+        path of a SMILES file whose directory holds the dataset cache 'processed_data.pkl' (a
+        torch-saved list of process_step1 dicts, read with weights_only=True).  The packed
+        form of that cache is kept beside it as 'processed_data.npz' and preferred when present.
+        `data` passes a list of process_step1 dicts (or a PackedMolecules) directly.
+        Building the cache from SMILES (process, :157-171) needs RDKit and is not done here."""
         super(BPEMolDataset, self).__init__()
         self.tokenizer = tokenizer
         self.device = torch.device(device)
@@ -27,7 +30,18 @@ class BPEMolDataset(torch.utils.data.Dataset):
                 self.packed = PackedMolecules.load(fname)
             else:
                 root, _ = os.path.split(fname)
-                data = torch.load(os.path.join(root, 'processed_data.pkl'), weights_only=True)
+                cache, pkl = os.path.join(root, 'processed_data.npz'), os.path.join(root, 'processed_data.pkl')
+                if os.path.exists(cache):
+                    self.packed = PackedMolecules.load(cache)
+                elif os.path.exists(pkl):
+                    self.packed = PackedMolecules.from_step1(load_step1_pickle(pkl))
+                    try:
+                        self.packed.save(cache)
+                    except OSError:
+                        pass
+                else:
+                    raise FileNotFoundError(f'neither {cache} nor {pkl} exists; creating the cache from '
+                                            f'{fname} is process_step1 (RDKit), outside this package')
         if data is not None:
             self.packed = data if isinstance(data, PackedMolecules) else PackedMolecules.from_step1(data)
         self.dpacked = self.packed.to_device(self.device)
@@ -96,6 +110,9 @@ class _Loader:
             yield self.dataset.collate_ids(order[i:i + self.batch_size], reference_layout=self.reference_layout)
 
 
-def get_dataloader(fname, tokenizer, batch_size, shuffle=False, num_workers=4, device='cuda', data=None):
+def get_dataloader(fname, tokenizer, batch_size, shuffle=False, num_workers=4, device='cuda', data=None,
+                   reference_layout=True, seed=None):
+    """reference_layout=False yields batches that carry only the compact layout the kernels
+    read (no padded [B,N] tensors, no host stop for the pair count): what training uses."""
     dataset = BPEMolDataset(fname, tokenizer, device=device, data=data)
-    return _Loader(dataset, batch_size, shuffle)
+    return _Loader(dataset, batch_size, shuffle, reference_layout=reference_layout, seed=seed)

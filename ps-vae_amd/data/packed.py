@@ -28,6 +28,22 @@ _INT_FIELDS = ('atom_off', 'atom_type', 'atom_pos', 'bond_off', 'bond_a', 'bond_
                'piece_off', 'piece_id', 'n_edge', 'n_inpiece', 'n_rng')
 
 
+def load_step1_pickle(path):
+    """The reference's dataset cache: a torch.save'd list of process_step1 dicts
+    ('processed_data.pkl', src/data/bpe_dataset.py:23-26, 170).  Read with
+    weights_only=True, so a file holding anything but lists / dicts / numbers / tensors is
+    refused instead of executed."""
+    data = torch.load(path, map_location='cpu', weights_only=True)
+    if not isinstance(data, (list, tuple)) or (len(data) and not isinstance(data[0], dict)):
+        raise ValueError(f'{path}: expected a list of process_step1 dicts')
+    keys = ('x', 'edge_index', 'edge_attr', 'props', 'pieces', 'groups')
+    for i, d in enumerate(data):
+        missing = [k for k in keys if k not in d]
+        if missing:
+            raise ValueError(f'{path}: molecule {i} lacks {missing}')
+    return [{k: (d[k].tolist() if torch.is_tensor(d[k]) else d[k]) for k in keys} for d in data]
+
+
 class PackedMolecules:
     def __init__(self, **arrays):
         for k in _INT_FIELDS:

@@ -17,20 +17,34 @@ import torch.distributed as dist
 
 
 class FlatGradSync:
-    def __init__(self, parameters, process_group=None):
+    def __init__(self, parameters, process_group=None, flatten_params=False):
+        """flatten_params: also move the parameters themselves into one flat buffer
+        (`flat_params`, every parameter becoming a view of it, values kept), so that an
+        optimiser can update the whole model with one kernel (optim.FlatAdam).  Call it after
+        the model sits on its device: `module.to()` would re-allocate the parameters."""
         self.params = [p for p in parameters if p.requires_grad]
         if not self.params:
             raise ValueError('no trainable parameters')
         dev, dtype = self.params[0].device, self.params[0].dtype
-        total = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(total, dtype=dtype, device=dev)
-        off = 0
-        self.views = []
+        if any(p.device != dev or p.dtype != dtype for p in self.params):
+            raise ValueError('parameters must share one device and dtype')
+        # every parameter starts on a multiple of 4 elements: its rows stay 16-byte aligned
+        offs, total = [], 0
         for p in self.params:
-            n = p.numel()
-            self.views.append(self.flat[off:off + n].view_as(p))
-            p.grad = self.views[-1]
-            off += n
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4
+        self.flat = torch.zeros(total, dtype=dtype, device=dev)
+        self.views = [self.flat[o:o + p.numel()].view_as(p) for o, p in zip(offs, self.params)]
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+        self.flat_params = None
+        if flatten_params:
+            self.flat_params = torch.zeros(total, dtype=dtype, device=dev)
+            with torch.no_grad():
+                for o, p in zip(offs, self.params):
+                    slot = self.flat_params[o:o + p.numel()].view_as(p)
+                    slot.copy_(p)
+                    p.data = slot
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
 
@@ -55,8 +69,10 @@ class FlatGradSync:
         if src:
             torch._foreach_copy_(dst, src)
 
-    def sync(self):
-        """Pack, then average the gradients over the ranks (one process: pack only)."""
+    def sync(self, average=True):
+        """Pack, then sum the gradients over the ranks and (average=True) divide by the world
+        size; optim.FlatAdam passes False and folds the division into its update kernel.
+        One process: pack only."""
         self.pack()
         if self.world > 1:
             if self.flat.is_cuda and dist.get_backend(self.group) == 'gloo':
@@ -66,7 +82,8 @@ class FlatGradSync:
                 self.flat.copy_(host)
             else:
                 dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-            self.flat.div_(self.world)
+            if average:
+                self.flat.div_(self.world)
 
     def clip_grad_norm_(self, max_norm):
         """Global-norm clipping on the flat buffer (torch.nn.utils.clip_grad_norm_ semantics:

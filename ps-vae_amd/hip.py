@@ -54,6 +54,8 @@ _SIGNATURES = {
     'psvae_link_ce_bwd_input': (_c_int, [_c_int, _c_int, _c_int, _p, _p, _p, _p, _c_int, _p]),
     'psvae_link_infer': (_c_int, [_c_int, _c_int, _p, _c_f32, _c_int, _p, _p, _p, _p]),
     'psvae_embed_trans_fwd': (_c_int, [_c_int, _c_int, _p, _p, _p, _c_int, _c_int, _c_int, _p, _p, _c_int, _p]),
+    'psvae_clip_adam_workspace_bytes': (_c_size, [_c_ll]),
+    'psvae_clip_adam_step': (_c_int, [_c_ll, _p, _p, _p, _p, _c_f32, _c_f32] + [_c_f64] * 5 + [_c_int, _c_int, _p, _p, _c_size, _p]),
     'psvae_assemble_links_workspace_bytes': (_c_size, [_c_int]),
     'psvae_assemble_links': (_c_int, [_c_int, _c_int] + [_p] * 12 + [_c_int, _c_int] + [_p] * 5 + [_c_size, _p]),
 }
@@ -488,3 +490,19 @@ def collate_fill(B, N, S, mol_ids, packed, offs, E, uniforms, keep_prob, atom_pa
         c('in_row_ptr', i32), c('in_col', i32), c('in_cls', u8),
         c('pair_src', i32), c('pair_dst', i32), c('pair_graph', i32), c('golden32', i32), _stream())
     _check(rc, 'psvae_collate_fill')
+
+
+def clip_adam_step(p, g, m, v, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0,
+                   max_norm=0.0, write_grad=True, norm_out=None):
+    """Scale + global-norm clip + Adam on flat f32 buffers (psvae_clip_adam_step)."""
+    L = lib()
+    n = p.numel()
+    if not (g.numel() == m.numel() == v.numel() == n):
+        raise ValueError('clip_adam_step: buffers differ in length')
+    nbytes = L.psvae_clip_adam_workspace_bytes(n)
+    ws = workspace(nbytes, p.device) if nbytes else None
+    f = torch.float32
+    _check(L.psvae_clip_adam_step(n, ptr(p, f), ptr(g, f), ptr(m, f), ptr(v, f), float(grad_scale), float(max_norm or 0.0),
+                                  float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
+                                  int(step), 1 if write_grad else 0, ptr(norm_out, f), ptr(ws), nbytes, _stream()),
+           'psvae_clip_adam_step')

@@ -1,0 +1,57 @@
+"""The optimiser tail on flat buffers: gradient exchange, global-norm clipping and Adam as two
+kernel launches over the whole model (psvae_clip_adam_step), in place of the per-step sequence
+of the reference's Trainer: clip_grad_norm_ (gradient_clip_val, src/train.py:47) and
+torch.optim.Adam (src/pl_models/ps_vae_model.py:123-127)."""
+import torch
+
+from . import hip
+from .dist import FlatGradSync
+
+
+class FlatAdam(torch.optim.Optimizer):
+    """Adam over a FlatGradSync whose parameters were flattened.  `step()` = pack the gradients
+    backward produced, all-reduce them over the ranks, divide by the world size, clip to
+    `max_norm` (None: no clipping) and update — the division, the clipping and the update being
+    one kernel pair.  A torch.optim.Optimizer, so lr schedulers (LambdaLR of
+    configure_optimizers) drive param_groups[0]['lr'] as usual."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=None,
+                 process_group=None):
+        sync = params if isinstance(params, FlatGradSync) else FlatGradSync(params, process_group,
+                                                                             flatten_params=True)
+        if sync.flat_params is None:
+            raise ValueError('FlatAdam needs FlatGradSync(..., flatten_params=True)')
+        if not sync.flat.is_cuda:
+            raise RuntimeError('FlatAdam runs on the GPU (there is no CPU fallback)')
+        super().__init__(sync.params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.sync = sync
+        self.max_norm = max_norm
+        self.exp_avg = torch.zeros_like(sync.flat_params)
+        self.exp_avg_sq = torch.zeros_like(sync.flat_params)
+        self.steps = 0
+        self.grad_norm = torch.zeros((), dtype=torch.float32, device=sync.flat.device)
+
+    def zero_grad(self, set_to_none=True):
+        self.sync.zero_grad()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        sync, group = self.sync, self.param_groups[0]
+        sync.sync(average=False)
+        self.steps += 1
+        hip.clip_adam_step(sync.flat_params, sync.flat, self.exp_avg, self.exp_avg_sq, self.steps, group['lr'],
+                           group['betas'], group['eps'], group['weight_decay'], grad_scale=1.0 / sync.world,
+                           max_norm=self.max_norm, write_grad=True, norm_out=self.grad_norm)
+        return loss
+
+    def state_dict(self):
+        return {'steps': self.steps, 'exp_avg': self.exp_avg.clone(), 'exp_avg_sq': self.exp_avg_sq.clone(),
+                'param_groups': [{k: v for k, v in g.items() if k != 'params'} for g in self.param_groups]}
+
+    def load_state_dict(self, state):
+        self.steps = int(state['steps'])
+        self.exp_avg.copy_(state['exp_avg'])
+        self.exp_avg_sq.copy_(state['exp_avg_sq'])
+        for g, saved in zip(self.param_groups, state['param_groups']):
+            g.update(saved)

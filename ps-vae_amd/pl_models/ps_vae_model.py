@@ -142,7 +142,14 @@ class PSVAEModel(nn.Module):
         return loss
 
     def configure_optimizers(self):
-        optimizer = torch.optim.Adam(self.parameters(), lr=self.config['lr'])
+        """src/pl_models/ps_vae_model.py:123-127.  On the GPU the optimiser is optim.FlatAdam:
+        the same Adam arithmetic on one flat parameter buffer, with the gradient exchange and
+        the Trainer's global-norm clipping folded into its step()."""
+        if self.device.type == 'cuda':
+            from ..optim import FlatAdam
+            optimizer = FlatAdam(self.parameters(), lr=self.config['lr'])
+        else:
+            optimizer = torch.optim.Adam(self.parameters(), lr=self.config['lr'])
         scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lambda=lambda epoch: 1 / (epoch + 1))
         return [optimizer], [scheduler]
 

@@ -1,0 +1,220 @@
+"""Training entry: the fit / test loop the reference gets from pytorch_lightning.Trainer
+(src/train.py:31-54), restated for a model that exposes the Lightning hooks
+(training_step, validation_step, test_step, configure_optimizers, global_step, log):
+
+  * per step: zero_grad, training_step, backward, global-norm clipping (gradient_clip_val,
+    :47), optimiser step, global_step += 1;
+  * per epoch: one pass over the validation loader (the batch-size weighted mean of the logged
+    'val_loss' is the monitored value), the schedulers of configure_optimizers stepped once
+    (LambdaLR 1 / (epoch + 1), src/pl_models/ps_vae_model.py:125-126), best-`monitor`
+    checkpoint (ModelCheckpoint(monitor), :32-34) and VAE early stopping
+    (src/utils/nn_utils.py:126-136: patience does not run while the KL weight is annealing);
+  * afterwards one pass over the test loader (trainer.test, :54).
+
+    python -m ps_vae_amd.train --train_set train.npz --valid_set valid.npz --test_set test.npz \
+        --vocab vocab.txt --save_dir ckpt --alpha 0.1 [the flags of src/train.py:57-111]
+"""
+import argparse
+import math
+import os
+import random
+
+import numpy as np
+import torch
+
+
+def setup_seed(seed):
+    """src/train.py:20-28."""
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+    np.random.seed(seed)
+    random.seed(seed)
+
+
+def finish_anneal_step(args):
+    """src/train.py:36, the same float expression (0.01 // 0.002 == 5.0: 4000 steps with the defaults)."""
+    return args.kl_warmup + (args.max_beta // args.step_beta - 1) * args.kl_anneal_iter
+
+
+class VAEEarlyStopping:
+    """EarlyStopping(monitor, mode='min', min_delta=0, patience) whose best score and wait
+    count are reset after every validation that happens before `finish_anneal_step`
+    optimisation steps (src/utils/nn_utils.py:126-136)."""
+
+    def __init__(self, finish_anneal_step, patience=3, min_delta=0.0):
+        self.finish_anneal_step = finish_anneal_step
+        self.patience, self.min_delta = patience, min_delta
+        self.best_score, self.wait_count = math.inf, 0
+        self.should_stop = False
+
+    def on_validation_end(self, global_step, current):
+        if not math.isfinite(current):          # Lightning's check_finite: stop on NaN / inf
+            self.should_stop = True
+        elif current < self.best_score - self.min_delta:
+            self.best_score, self.wait_count = current, 0
+        else:
+            self.wait_count += 1
+            if self.wait_count >= self.patience:
+                self.should_stop = True
+        if global_step < self.finish_anneal_step:     # a stop already requested above stands, as upstream
+            self.best_score, self.wait_count = math.inf, 0
+        return self.should_stop
+
+
+class ModelCheckpoint:
+    """Keeps the checkpoint with the lowest monitored value (save_top_k = 1): the model's
+    state_dict under the reference's keys plus epoch / global_step / monitor value."""
+
+    def __init__(self, dirpath, monitor='val_loss'):
+        self.dirpath, self.monitor = dirpath, monitor
+        self.best_score, self.best_path = math.inf, None
+
+    def on_validation_end(self, model, epoch, global_step, current, optimizer=None):
+        if self.dirpath is None or not current < self.best_score:
+            return None
+        os.makedirs(self.dirpath, exist_ok=True)
+        path = os.path.join(self.dirpath, f'epoch={epoch}-step={global_step}.ckpt')
+        payload = {'state_dict': {k: v.detach().cpu() for k, v in model.state_dict().items()},
+                   'epoch': epoch, 'global_step': global_step, self.monitor: current}
+        if optimizer is not None:
+            payload['optimizer'] = optimizer.state_dict()
+        torch.save(payload, path)
+        if self.best_path is not None and self.best_path != path and os.path.exists(self.best_path):
+            os.remove(self.best_path)
+        self.best_score, self.best_path = current, path
+        return path
+
+
+def _batch_size(batch):
+    n = getattr(batch, 'batch_size', None)
+    if n is None:
+        n = len(batch['x']) if hasattr(batch, '__getitem__') else 1
+    return int(n)
+
+
+def _logged(model, name):
+    v = model.logged[name]
+    return float(v.detach()) if torch.is_tensor(v) else float(v)
+
+
+@torch.no_grad()
+def evaluate(model, loader, hook, name):
+    """Batch-size weighted mean of the value `hook` logs under `name` over `loader`."""
+    was_training = model.training
+    model.eval()
+    total, count = 0.0, 0
+    for i, batch in enumerate(loader):
+        getattr(model, hook)(batch, i)
+        n = _batch_size(batch)
+        total += _logged(model, name) * n
+        count += n
+    model.train(was_training)
+    return total / count if count else math.nan
+
+
+def fit(model, train_loader, valid_loader=None, test_loader=None, max_epochs=6, grad_clip=10.0, patience=3,
+        finish_anneal=0, monitor='val_loss', save_dir=None, on_step=None):
+    """Returns a dict: epochs run, global_step, per-epoch monitor values and learning rates,
+    best checkpoint path, test loss."""
+    optimizers, schedulers = model.configure_optimizers()
+    opt = optimizers[0]
+    fused_tail = hasattr(opt, 'sync')          # optim.FlatAdam: exchange + clip + Adam in step()
+    if fused_tail:
+        opt.max_norm = grad_clip
+    stopper = VAEEarlyStopping(finish_anneal, patience=patience)
+    ckpt = ModelCheckpoint(save_dir, monitor)
+    history = {'monitor': [], 'lr': [], 'stopped_early': False}
+    model.train()
+    epoch = 0
+    for epoch in range(max_epochs):
+        history['lr'].append(opt.param_groups[0]['lr'])
+        for i, batch in enumerate(train_loader):
+            opt.zero_grad()
+            loss = model.training_step(batch, i)
+            loss.backward()
+            if not fused_tail and grad_clip:
+                torch.nn.utils.clip_grad_norm_(model.parameters(), grad_clip)
+            opt.step()
+            model.global_step += 1
+            if on_step is not None:
+                on_step(model, loss)
+        if valid_loader is not None:
+            current = evaluate(model, valid_loader, 'validation_step', monitor)
+            history['monitor'].append(current)
+            ckpt.on_validation_end(model, epoch, model.global_step, current, opt)
+            stopper.on_validation_end(model.global_step, current)
+        for sched in schedulers:
+            sched.step()
+        if stopper.should_stop:
+            history['stopped_early'] = True
+            break
+    history.update(epochs=epoch + 1, global_step=model.global_step, best_path=ckpt.best_path,
+                   best_score=ckpt.best_score)
+    if test_loader is not None:
+        history['test_loss'] = evaluate(model, test_loader, 'test_step', 'test_loss')
+    return history
+
+
+def load_checkpoint(model, path, optimizer=None):
+    """Restore a ModelCheckpoint file (tensors only: loaded with weights_only=True)."""
+    payload = torch.load(path, map_location='cpu', weights_only=True)
+    model.load_state_dict(payload['state_dict'])
+    model.global_step = int(payload.get('global_step', 0))
+    if optimizer is not None and 'optimizer' in payload:
+        optimizer.load_state_dict(payload['optimizer'])
+    return payload
+
+
+def parse(argv=None):
+    """The flags of src/train.py:57-111."""
+    ap = argparse.ArgumentParser(description='training overall model for molecule generation')
+    for name in ('train_set', 'valid_set', 'test_set', 'vocab', 'save_dir'):
+        ap.add_argument('--' + name, type=str, required=True)
+    ap.add_argument('--shuffle', action='store_true')
+    ap.add_argument('--batch_size', type=int, default=32)
+    ap.add_argument('--lr', type=float, default=1e-3)
+    ap.add_argument('--alpha', type=float, required=True)
+    ap.add_argument('--beta', type=float, default=0)
+    ap.add_argument('--step_beta', type=float, default=0.002)
+    ap.add_argument('--max_beta', type=float, default=0.01)
+    ap.add_argument('--kl_warmup', type=int, default=0)
+    ap.add_argument('--kl_anneal_iter', type=int, default=1000)
+    ap.add_argument('--num_workers', type=int, default=4, help='accepted for compatibility: collation runs on the GPU')
+    ap.add_argument('--gpus', default=None)
+    ap.add_argument('--epochs', type=int, default=6)
+    ap.add_argument('--patience', type=int, default=3)
+    ap.add_argument('--grad_clip', type=float, default=10.0)
+    ap.add_argument('--monitor', type=str, default='val_loss')
+    ap.add_argument('--props', type=str, nargs='+', choices=['qed', 'sa', 'logp'], default=['qed', 'logp'])
+    ap.add_argument('--predictor_hidden_dim', type=int, default=200)
+    ap.add_argument('--node_hidden_dim', type=int, default=300)
+    ap.add_argument('--graph_embedding_dim', type=int, default=400)
+    ap.add_argument('--latent_dim', type=int, default=56)
+    ap.add_argument('--max_pos', type=int, default=50)
+    ap.add_argument('--atom_embedding_dim', type=int, default=50)
+    ap.add_argument('--piece_embedding_dim', type=int, default=100)
+    ap.add_argument('--pos_embedding_dim', type=int, default=50)
+    ap.add_argument('--piece_hidden_dim', type=int, default=200)
+    return ap.parse_args(argv)
+
+
+def main(argv=None):
+    from .data import bpe_dataset
+    from .pl_models import PSVAEModel
+    from .utils.nn_utils import build_config
+    from .utils.tokenizer import Tokenizer
+    setup_seed(2021)
+    args = parse(argv)
+    tokenizer = Tokenizer(args.vocab)
+    loaders = [bpe_dataset.get_dataloader(f, tokenizer, batch_size=args.batch_size, shuffle=sh, reference_layout=False)
+               for f, sh in ((args.train_set, args.shuffle), (args.valid_set, False), (args.test_set, False))]
+    model = PSVAEModel(build_config(args, tokenizer), tokenizer).to('cuda')
+    result = fit(model, *loaders, max_epochs=args.epochs, grad_clip=args.grad_clip, patience=args.patience,
+                 finish_anneal=finish_anneal_step(args), monitor=args.monitor, save_dir=args.save_dir)
+    print(result)
+    return result
+
+
+if __name__ == '__main__':
+    main()

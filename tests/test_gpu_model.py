@@ -79,6 +79,12 @@ def test_small_model_against_reference_golden(tokenizer, path):
                                reference_layout=False)
         assert batch.compact is not None and 'x' not in batch
 
+    flat_opt = None
+    if path == 'compact':
+        # the product's optimiser tail: flat parameters, clip + Adam in one kernel pair
+        (flat_opt,), _ = model.configure_optimizers()
+        flat_opt.max_norm = 10.0
+        flat_opt.zero_grad()
     pred_loss, (losses, accus) = model(batch, return_accu=True, eps=eps)
     rec, piece, edge, kl = losses
     loss = model.weighted_loss(pred_loss, rec, kl)
@@ -93,12 +99,56 @@ def test_small_model_against_reference_golden(tokenizer, path):
             assert p.grad is None, k
             continue
         close(p.grad, torch.from_numpy(gold[f'grad/{k}']), rel=2e-5, what=f'grad {k}')
-    opt = torch.optim.Adam(model.parameters(), lr=cfg['lr'])
-    total = torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
+    if flat_opt is not None:
+        flat_opt.step()
+        total = flat_opt.grad_norm
+    else:
+        opt = torch.optim.Adam(model.parameters(), lr=cfg['lr'])
+        total = torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
+        opt.step()
     np.testing.assert_allclose(total.item(), gold['grad_total_norm'], rtol=1e-5)
-    opt.step()
     for k, v in model.state_dict().items():
         close(v, torch.from_numpy(gold[f'after_step/{k}']), rel=2e-5, what=f'after step {k}')
+
+
+def test_flat_adam_follows_torch_adam_with_clipping():
+    """Twenty steps of optim.FlatAdam (scale + clip + Adam on flat buffers) beside
+    clip_grad_norm_ + torch.optim.Adam in float64 on the same gradients, clipping active on some
+    steps and not on others, the learning rate changed on the way."""
+    from ps_vae_amd.optim import FlatAdam
+    d = dev()
+    g = torch.Generator().manual_seed(0)
+    shapes = [(300, 200), (300,), (7, 5), (1,), (1200, 13), (3,)]
+    ref = [torch.nn.Parameter(torch.randn(*s, generator=g, dtype=torch.float64)) for s in shapes]
+    mine = [torch.nn.Parameter(p.detach().float().to(d)) for p in ref]
+    ref_opt = torch.optim.Adam(ref, lr=1e-3)
+    opt = FlatAdam(mine, lr=1e-3, max_norm=10.0)
+    assert all(p.data_ptr() % 16 == 0 for p in mine)
+    for step in range(20):
+        scale = 100.0 if step % 3 == 0 else 0.01          # norm above / below the clipping threshold
+        grads = [torch.randn(*s, generator=g, dtype=torch.float64) * scale for s in shapes]
+        if step == 10:
+            for o in (ref_opt, opt):
+                o.param_groups[0]['lr'] = 5e-4
+        opt.zero_grad()
+        for p, q, gr in zip(ref, mine, grads):
+            p.grad = gr.clone()
+            q.grad = gr.float().to(d)
+        if step % 5 == 4:
+            ref[3].grad = None
+            mine[3].grad = None                            # a parameter without a gradient this step
+            # (torch skips it; the flat update sees a zero gradient: the moments decay, which
+            # moves the parameter by its running mean - compare everything else)
+        want_norm = torch.nn.utils.clip_grad_norm_([p for p in ref if p.grad is not None], 10.0)
+        ref_opt.step()
+        opt.step()
+        np.testing.assert_allclose(opt.grad_norm.item(), want_norm.item(), rtol=2e-6)
+        for i, (p, q) in enumerate(zip(ref, mine)):
+            if i == 3:
+                continue
+            close(q, p, rel=2e-6, what=f'step {step} param {i}')
+            if p.grad is not None:
+                close(q.grad, p.grad, rel=2e-6, what=f'step {step} clipped grad {i}')
 
 
 def test_default_width_model_against_reference_golden(tokenizer):
@@ -224,7 +274,6 @@ def test_loss_curve_follows_the_oracle_over_30_steps(tokenizer):
     from ps_vae_amd.data.collate import collate_packed
     from ps_vae_amd.data.packed import PackedMolecules
     from ps_vae_amd.data.synthetic import synthetic_step1
-    from ps_vae_amd.dist import FlatGradSync
     steps, B = 30, 32
     sched = dict(kl_warmup=5, kl_anneal_iter=5, step_beta=0.002, max_beta=0.01)
     cfg = model_ref.default_config(tokenizer, **sched)
@@ -234,8 +283,8 @@ def test_loss_curve_follows_the_oracle_over_30_steps(tokenizer):
     ref_opt = torch.optim.Adam(ref.parameters(), lr=cfg['lr'])
     ref64_opt = torch.optim.Adam(ref64.parameters(), lr=cfg['lr'])
     model, hcfg = hip_model(tokenizer, state=ref.state_dict(), **sched)
-    sync = FlatGradSync(model.parameters())
-    opt = torch.optim.Adam(model.parameters(), lr=hcfg['lr'], fused=True)
+    (opt,), _ = model.configure_optimizers()      # optim.FlatAdam: exchange + clip + Adam on flat buffers
+    opt.max_norm = 10.0
     mols = synthetic_step1(steps * B, seed=77, shape='zinc')
     rng = np.random.default_rng(9)
     gen = torch.Generator().manual_seed(4)
@@ -258,13 +307,11 @@ def test_loss_curve_follows_the_oracle_over_30_steps(tokenizer):
                                atom_pad=tokenizer.atom_pad_idx(), piece_pad=tokenizer.pad_idx(),
                                reference_layout=False)
         assert batch.num_uniforms == used
-        sync.zero_grad()
+        opt.zero_grad()
         pred_loss, (rec, piece, edge, kl) = model(batch, eps=eps.to(dev()))
         assert abs(model.cal_beta() - beta_ref) < 1e-12
         loss = model.weighted_loss(pred_loss, rec, kl)
         loss.backward()
-        sync.sync()
-        sync.clip_grad_norm_(10.0)
         opt.step()
         model.global_step += 1
         got = dict(zip(names, (v.item() for v in (loss, pred_loss, rec, piece, edge, kl))))

@@ -138,3 +138,36 @@ def test_cnt_atom_and_piece_atom_counts(tmp_path):
     counts = tok.piece_atom_counts()
     assert counts[:3] == [1, 2, 3] and counts[tok.pad_idx()] == 0 and counts[tok.end_idx()] == 0
 
+
+
+def test_processed_data_pkl_round_trip(tmp_path, tokenizer):
+    """The reference's dataset cache ('processed_data.pkl': torch.save of the process_step1
+    dicts, src/data/bpe_dataset.py:23-26, 170) -> BPEMolDataset -> packed arrays, through the
+    converter script in both directions."""
+    import subprocess
+    import sys
+    from ps_vae_amd.data.bpe_dataset import BPEMolDataset
+    from ps_vae_amd.data.packed import PackedMolecules
+    from ps_vae_amd.data.synthetic import synthetic_step1
+    step1 = synthetic_step1(40, seed=5, shape='zinc') + synthetic_step1(10, seed=6, shape='qm9')
+    want = PackedMolecules.from_step1(step1)
+    torch.save(step1, tmp_path / 'processed_data.pkl')
+    (tmp_path / 'train.txt').write_text('C\n')
+    ds = BPEMolDataset(str(tmp_path / 'train.txt'), tokenizer, device='cpu')
+    assert len(ds) == 50
+    for k in ('atom_off', 'atom_type', 'atom_pos', 'bond_off', 'bond_a', 'bond_b', 'bond_cls', 'piece_off',
+              'piece_id', 'n_edge', 'n_inpiece', 'n_rng', 'props'):
+        assert np.array_equal(getattr(ds.packed, k), getattr(want, k)), k
+    assert (tmp_path / 'processed_data.npz').exists()            # packed cache written beside the pickle
+    ds2 = BPEMolDataset(str(tmp_path / 'train.txt'), tokenizer, device='cpu')
+    assert np.array_equal(ds2.packed.atom_type, want.atom_type)
+    # the converter script, both directions
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'pkl_to_packed.py')
+    subprocess.run([sys.executable, tool, str(tmp_path / 'processed_data.pkl'), str(tmp_path / 'a.npz')], check=True)
+    subprocess.run([sys.executable, tool, '--to-pkl', str(tmp_path / 'a.npz'), str(tmp_path / 'back.pkl')], check=True)
+    back = torch.load(tmp_path / 'back.pkl', weights_only=True)
+    again = PackedMolecules.from_step1(back)
+    assert np.array_equal(again.atom_pos, want.atom_pos) and np.array_equal(again.bond_cls, want.bond_cls)
+    assert np.array_equal(again.piece_id, want.piece_id) and np.allclose(again.props, want.props)
+    with pytest.raises(FileNotFoundError):
+        BPEMolDataset(str(tmp_path / 'nowhere' / 'train.txt'), tokenizer, device='cpu')
