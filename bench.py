@@ -36,25 +36,26 @@ def parse():
     ap.add_argument('--batch', type=int, default=4096, help='molecules per GPU per step')
     ap.add_argument('--dataset', type=int, default=0, help='synthetic molecules per rank (default 4x batch)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-sub-records', action='store_true', help='skip the batch-32 and 10k-generation sub-records')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl = RCCL; gloo for rehearsals)')
     ap.add_argument('--device', type=int, default=-1,
                     help='GPU index for every rank (rehearsal of N ranks on one GPU); default LOCAL_RANK')
     ap.add_argument('--gemm-shapes', action='store_true', help='per-shape GEMM timing table on stderr')
     ap.add_argument('--cpu-batch', type=int, default=256)
-    ap.add_argument('--cpu-steps', type=int, default=40, help='CPU-baseline sample: about 10 s of host work')
+    ap.add_argument('--cpu-steps', type=int, default=30, help='CPU-baseline headline sample: about 8 s of host work')
     return ap.parse_args()
 
 
-def make_dataset(num, seed, tok, device):
+def make_dataset(num, seed, tok, device, shape='zinc'):
     import ps_vae_amd  # noqa: F401
     from ps_vae_amd.data.bpe_dataset import BPEMolDataset
     from ps_vae_amd.data.packed import PackedMolecules
     from ps_vae_amd.data.synthetic import synthetic_step1
-    cache = f'/tmp/psvae_synth_zinc_{num}_{seed}.npz'
+    cache = f'/tmp/psvae_synth_{shape}_{num}_{seed}.npz'
     if os.path.exists(cache):
         packed = PackedMolecules.load(cache)
     else:
-        packed = PackedMolecules.from_step1(synthetic_step1(num, seed=seed, shape='zinc'))
+        packed = PackedMolecules.from_step1(synthetic_step1(num, seed=seed, shape=shape))
         try:
             packed.save(cache)
         except OSError:
@@ -62,21 +63,21 @@ def make_dataset(num, seed, tok, device):
     return BPEMolDataset(None, tok, device=device, data=packed)
 
 
-def cpu_baseline(tok, batch, steps):
-    """The CPU oracle (oracle/: pure-Python collation restatement + plain PyTorch fp32 model,
-    clip, Adam) on this machine's host cores, on a bounded sample of the same workload."""
+def _cpu_leg(tok, shape, batch, steps, seed):
+    """One CPU-oracle leg: `steps` train steps of `batch` molecules (+1 warm-up step); returns
+    (collation seconds, model seconds)."""
     from oracle import collate_ref, model_ref
     from ps_vae_amd.data.synthetic import synthetic_step1
     torch.manual_seed(2021)
     model = model_ref.PSVAEModel(model_ref.default_config(tok), tok)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     rng = np.random.default_rng(0)
-    mols = synthetic_step1(batch * (steps + 1), seed=99, shape='zinc')
+    mols = synthetic_step1(batch * (steps + 1), seed=seed, shape=shape)
     t_collate = t_model = 0.0
     for s in range(steps + 1):
         chunk = mols[s * batch:(s + 1) * batch]
         t0 = time.perf_counter()
-        b, _ = collate_ref.collate(chunk, rng.random(700 * batch), piece_pad=tok.pad_idx())
+        b, _ = collate_ref.collate(chunk, rng.random(1500 * batch), piece_pad=tok.pad_idx())
         tb = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in b.items()}
         t1 = time.perf_counter()
         model_ref.train_step(model, opt, tb, torch.randn(batch, 56))
@@ -84,25 +85,115 @@ def cpu_baseline(tok, batch, steps):
         if s > 0:            # first step is warm-up
             t_collate += t1 - t0
             t_model += t2 - t1
-    total = t_collate + t_model
-    return {'value': round(batch * steps / total, 2), 'unit': 'molecules/s', 'cores': torch.get_num_threads(),
-            'kind': 'port',
-            'sample': f'{steps} train steps of batch {batch} (same synthetic ZINC-shaped generator), '
-                      f'collation + forward + backward + clip + Adam, after 1 warm-up step',
-            'collate_molecules_per_s_1core': round(batch * steps / t_collate, 2),
-            'model_step_molecules_per_s': round(batch * steps / t_model, 2)}
+    return t_collate, t_model
 
 
-def pmc_traffic():
+def cpu_baseline(tok, batch, steps):
+    """The CPU oracle (oracle/: pure-Python collation restatement + plain PyTorch fp32 model,
+    clip, Adam) on this machine's host cores, on bounded samples of the same workloads: the
+    headline sample at `batch` (default 256), plus batch 32 on ZINC-shaped and QM9-shaped
+    molecules (BASELINE.json configs[1] and configs[0], the reference's own CPU case).
+    Collation is single-threaded Python, as one DataLoader worker of the reference is."""
+    cores = torch.get_num_threads()
+    tc, tm = _cpu_leg(tok, 'zinc', batch, steps, 99)
+    total = tc + tm
+    out = {'value': round(batch * steps / total, 2), 'unit': 'molecules/s', 'cores': cores, 'kind': 'port',
+           'sample': f'{steps} train steps of batch {batch} (same synthetic ZINC-shaped generator), '
+                     f'collation + forward + backward + clip + Adam, after 1 warm-up step',
+           'collate_molecules_per_s_1core': round(batch * steps / tc, 2),
+           'model_step_molecules_per_s': round(batch * steps / tm, 2)}
+    for name, shape, b, n in (('b32_zinc', 'zinc', 32, 60), ('b32_qm9', 'qm9', 32, 120)):
+        tc, tm = _cpu_leg(tok, shape, b, n, 98)
+        out[name] = {'value': round(b * n / (tc + tm), 2), 'unit': 'molecules/s', 'cores': cores,
+                     'sample': f'{n} train steps of batch {b}, {shape.upper()}-shaped',
+                     'collate_molecules_per_s_1core': round(b * n / tc, 2),
+                     'model_step_molecules_per_s': round(b * n / tm, 2),
+                     'with_4_collation_workers_molecules_per_s': round(b * n / (max(tc / 4, tm)), 2)}
+    return out
+
+
+def pmc_traffic(batch):
     """HBM bytes per launch from the newest committed counter pass (profiles/*_traffic.json:
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this same command, corrected as
-    tools/pmc_traffic.py documents); None when no such file travels with the tree."""
+    tools/pmc_traffic.py documents) whose batch size equals this run's; returns
+    (per-kernel dict or None, description of the source).  The counters come from a separate
+    profiled run of the build named in the file, not from this run."""
     import glob
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', '*_traffic.json')))
-    if not files:
-        return None
-    with open(files[-1]) as f:
-        return json.load(f)
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_traffic.json')))
+    for path in reversed(files):
+        with open(path) as f:
+            data = json.load(f)
+        meta = data.get('_meta', {})
+        if int(meta.get('batch', 4096)) == int(batch):
+            return data, {'file': os.path.relpath(path, ROOT), 'build': meta.get('build', 'unknown'),
+                          'batch': int(meta.get('batch', 4096)),
+                          'note': 'separate rocprofv3 --pmc passes over bench.py at this batch size'}
+    return None, None
+
+
+def small_batch_record(model_factory, tok, shape, B, steps, warmup, dev):
+    """A short training run at batch B (BASELINE.json configs[0] / configs[1] shapes) on the
+    same code path: molecules/s, ms per step and C-ABI calls per step."""
+    from ps_vae_amd import hip
+    model, opt = model_factory()
+    dataset = make_dataset(64 * B, 7, tok, dev, shape=shape)
+    rng = np.random.default_rng(3)
+
+    def step():
+        batch = dataset.collate_ids(rng.choice(len(dataset), size=B, replace=False))
+        opt.zero_grad()
+        model.training_step(batch, 0).backward()
+        opt.step()
+        model.global_step += 1
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    calls0 = hip.CALLS
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {'value': round(B * steps / dt, 1), 'unit': 'molecules/s', 'ms_per_step': round(dt / steps * 1e3, 3),
+            'batch': B, 'shape': shape, 'steps': steps, 'abi_calls_per_step': (hip.CALLS - calls0) // steps}
+
+
+def generation_record(model, dev, n_mol=10000, reps=3):
+    """BASELINE.json configs[4]: n_mol latents -> piece sampling -> fragment graphs -> link
+    prediction over all cross-fragment atom pairs -> greedy assembly (device work of
+    VAEPieceDecoder.inference_batch; host packaging of the result lists excluded)."""
+    dec = model.decoder
+    gen = torch.Generator(device=dev).manual_seed(11)
+    z = torch.randn(n_mol, dec.latent_dim, device=dev, generator=gen)
+    u = torch.rand(n_mol, 50, device=dev, generator=gen)
+
+    def run():
+        ids, lengths = dec.sample_pieces_batch(z, 30, 1.0, uniforms=u)
+        g = dec.expand_pieces(ids, lengths)
+        links = dec.infer_links_batch(z, g['x'], g['x_pieces'], g['x_pos'], g['node_off'], g['csr_in'], g['block0'], 0.5)
+        asm = dec.assemble_links_batch(links, g['x'], g['node_off'], g['csr_in'], g['block0'], g['n_blocks'])
+        return g, links, asm
+
+    with torch.no_grad():
+        g, links, asm = run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            run()
+        torch.cuda.synchronize()
+        t_all = (time.perf_counter() - t0) / reps
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            dec.infer_links_batch(z, g['x'], g['x_pieces'], g['x_pos'], g['node_off'], g['csr_in'], g['block0'], 0.5)
+        torch.cuda.synchronize()
+        t_link = (time.perf_counter() - t0) / reps
+    pairs = int(links['conf'].numel())
+    return {'molecules': n_mol, 'atoms': int(g['x'].numel()), 'candidate_pairs': pairs,
+            'value': round(n_mol / t_all, 1), 'unit': 'molecules/s', 'ms_total': round(t_all * 1e3, 2),
+            'link_prediction_ms': round(t_link * 1e3, 2), 'link_prediction_pairs_per_s': round(pairs / t_link, 1),
+            'note': 'random-init weights, synthetic 300-piece vocabulary; sampling + expansion + link prediction '
+                    'over all cross-fragment pairs + greedy assembly'}
 
 
 def main():
@@ -210,8 +301,10 @@ def main():
                        'atoms_per_step': stats['V'] // args.steps, 'pairs_per_step': stats['P'] // args.steps},
             'rec_loss_last_step': round(final_loss, 5),
         }
-        out.update(hip.roofline_report(prof, HBM_PEAK_GBS, MFMA_F32_PEAK_TFLOPS, pmc_traffic()))
-        shared = hip.roofline_report(prof_shared, HBM_PEAK_GBS, MFMA_F32_PEAK_TFLOPS, pmc_traffic())
+        traffic, traffic_source = pmc_traffic(B)
+        out.update(hip.roofline_report(prof, HBM_PEAK_GBS, MFMA_F32_PEAK_TFLOPS, traffic))
+        out['traffic_source'] = traffic_source
+        shared = hip.roofline_report(prof_shared, HBM_PEAK_GBS, MFMA_F32_PEAK_TFLOPS, traffic)
         out['roofline_two_streams'] = {k: shared[k] for k in ('roofline_mfma', 'roofline_hbm', 'roofline_hbm_bwd')
                                        if k in shared}
         out['roofline_note'] = ('roofline*: event brackets on timed steps 0, 16, 32, ..., which run on one '
@@ -222,6 +315,18 @@ def main():
             print('M N K A-contig B-contig masked rowsum launches ms TFLOP/s', file=sys.stderr)
             for row in hip.gemm_shape_table(prof):
                 print(' '.join(str(v) for v in row), file=sys.stderr)
+        if world == 1 and not args.no_sub_records:
+            # the other single-GPU configurations of BASELINE.json on the same build (not the headline)
+            def factory():
+                torch.manual_seed(2021)
+                m = PSVAEModel(build_config(cfg_args, tok), tok).to(dev)
+                (o,), _ = m.configure_optimizers()
+                o.max_norm = cfg_args.grad_clip
+                return m, o
+            del dataset
+            out['b32'] = small_batch_record(factory, tok, 'zinc', 32, 200, 30, dev)
+            out['b32_qm9'] = small_batch_record(factory, tok, 'qm9', 32, 200, 30, dev)
+            out['infer_10k'] = generation_record(model, dev)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(tok, args.cpu_batch, args.cpu_steps)
         print(json.dumps(out), flush=True)

@@ -248,6 +248,16 @@ int psvae_pair_gather_bwd(int B, int H, int L, const float *g_feats,
                           const int32_t *node_begin, const int32_t *node_end,
                           float *g_h, int ldgh, float *g_z, int ldgz, void *stream);
 
+/* First link-predictor layer on a split weight, for inference over ALL candidate pairs
+ * (src/modules/vae_piece_decoder.py:224-233): with W1 = [Wa | Wb | Wc] cut at the blocks of
+ * [h_src | h_dst | z], W1 feats[p] + b1 = (h Wa^T)[src[p]] + (h Wb^T)[dst[p]] + (z Wc^T + b1)[graph[p]],
+ * so the three products run once per node / per graph (psvae_gemm_f32) and this kernel only
+ * gathers, adds and applies `act`: out[p] = act(a[src[p]] + b[dst[p]] + c[graph[p]]), rows of F
+ * floats (F and every row stride multiples of 4). */
+int psvae_pair_combine_fwd(int P, int F, const float *a, int lda, const float *b, int ldb,
+                           const float *c, int ldc, const int32_t *src, const int32_t *dst,
+                           const int32_t *graph, int act, float *out, int ldo, void *stream);
+
 /* ------------------------------------------------------------------------------------
  * Two Linear layers with no activation between them as one affine map — the link
  * predictor's MLP output layer followed by the class layer

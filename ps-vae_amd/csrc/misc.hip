@@ -219,6 +219,26 @@ __global__ void pair_gather_fwd_kernel(int P, int h4, int l4, const float4 *__re
     }
 }
 
+// out[p] = act(a[src[p]] + b[dst[p]] + c[graph[p]]): the first link-predictor layer after its
+// weight has been split by input block (h_src | h_dst | z), so that the three products run once
+// per node / per graph instead of once per pair.
+__global__ void pair_combine_fwd_kernel(int P, int f4, const float4 *__restrict__ a, int lda4,
+                                        const float4 *__restrict__ b, int ldb4, const float4 *__restrict__ c,
+                                        int ldc4, const int32_t *__restrict__ src, const int32_t *__restrict__ dst,
+                                        const int32_t *__restrict__ graph, int relu, float4 *__restrict__ out,
+                                        int ldo4) {
+    const long long total = (long long)P * f4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int p = (int)(i / f4), f = (int)(i - (long long)p * f4);
+        const float4 u = a[(long long)src[p] * lda4 + f], v = b[(long long)dst[p] * ldb4 + f];
+        const float4 w = c[(long long)graph[p] * ldc4 + f];
+        float4 o = make_float4((u.x + v.x) + w.x, (u.y + v.y) + w.y, (u.z + v.z) + w.z, (u.w + v.w) + w.w);
+        if (relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
+        out[(long long)p * ldo4 + f] = o;
+    }
+}
+
 // One workgroup per graph.  Pairs of the graph are staged CHUNK at a time in LDS (node ids
 // local to the graph); thread (slot, c) sums column c of the matching feature rows for nodes
 // slot, slot+slots, ...  The order of the sum is the pair order: deterministic.
@@ -660,6 +680,25 @@ extern "C" int psvae_pair_gather_fwd(int P, int H, int L, const float *h, int ld
                        H / 4, L / 4, (const float4 *)h, ldh / 4, (const float4 *)z, ldz / 4, src, dst, graph,
                        (float4 *)feats);
     PSVAE_CHECK_LAUNCH("psvae_pair_gather_fwd");
+    return PSVAE_OK;
+}
+
+extern "C" int psvae_pair_combine_fwd(int P, int F, const float *a, int lda, const float *b, int ldb, const float *c,
+                                      int ldc, const int32_t *src, const int32_t *dst, const int32_t *graph,
+                                      int act, float *out, int ldo, void *stream) {
+    const char *fn = "psvae_pair_combine_fwd";
+    PSVAE_REQUIRE(P >= 0 && F > 0 && F % 4 == 0, PSVAE_EINVAL, "%s: F=%d must be a positive multiple of 4", fn, F);
+    PSVAE_REQUIRE(act == PSVAE_ACT_NONE || act == PSVAE_ACT_RELU, PSVAE_EINVAL, "%s: bad act %d", fn, act);
+    if (P == 0) return PSVAE_OK;
+    PSVAE_REQUIRE(a && b && c && src && dst && graph && out, PSVAE_EINVAL, "%s: null operand", fn);
+    PSVAE_REQUIRE(psvae_aligned16(a) && psvae_aligned16(b) && psvae_aligned16(c) && psvae_aligned16(out), PSVAE_EINVAL,
+                  "%s: operands must be 16-byte aligned", fn);
+    PSVAE_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 && ldo % 4 == 0 && lda >= F && ldb >= F && ldc >= F &&
+                      ldo >= F, PSVAE_EINVAL, "%s: bad row stride", fn);
+    hipLaunchKernelGGL(pair_combine_fwd_kernel, dim3(grid_for((long long)P * (F / 4), 256, 16384)), dim3(256), 0,
+                       (hipStream_t)stream, P, F / 4, (const float4 *)a, lda / 4, (const float4 *)b, ldb / 4,
+                       (const float4 *)c, ldc / 4, src, dst, graph, act, (float4 *)out, ldo / 4);
+    PSVAE_CHECK_LAUNCH(fn);
     return PSVAE_OK;
 }
 

@@ -35,8 +35,11 @@ class FlatGradSync:
             total += (p.numel() + 3) // 4 * 4
         self.flat = torch.zeros(total, dtype=dtype, device=dev)
         self.views = [self.flat[o:o + p.numel()].view_as(p) for o, p in zip(offs, self.params)]
-        for p, v in zip(self.params, self.views):
-            p.grad = v
+        with torch.no_grad():
+            for p, v in zip(self.params, self.views):
+                if p.grad is not None:        # gradients that already exist move into the buffer
+                    v.copy_(p.grad)
+                p.grad = v
         self.flat_params = None
         if flatten_params:
             self.flat_params = torch.zeros(total, dtype=dtype, device=dev)

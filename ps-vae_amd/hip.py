@@ -37,6 +37,8 @@ _SIGNATURES = {
     'psvae_gemm_f32_workspace_bytes': (_c_size, [_c_int, _c_int, _c_int, _c_int]),
     'psvae_gemm_f32': (_c_int, [_c_int, _c_int, _c_int, _p, _p, _c_i64, _c_i64, _p, _c_i64, _c_i64, _p, _c_i64,
                                 _p, _p, _p, _c_int, _c_int, _c_int, _p, _c_size, _p]),
+    'psvae_pair_combine_fwd': (_c_int, [_c_int, _c_int, _p, _c_int, _p, _c_int, _p, _c_int, _p, _p, _p, _c_int, _p,
+                                        _c_int, _p]),
     'psvae_affine_merge_fwd': (_c_int, [_c_int, _c_int, _c_int, _p, _p, _p, _p, _p, _p, _p]),
     'psvae_affine_merge_bwd': (_c_int, [_c_int, _c_int, _c_int, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     'psvae_colsum_workspace_bytes': (_c_size, [_c_int, _c_int]),
@@ -82,7 +84,12 @@ def lib():
     return _lib
 
 
+CALLS = 0   # C-ABI calls made so far (bench.py reports calls per step)
+
+
 def _check(rc, name):
+    global CALLS
+    CALLS += 1
     if rc != 0:
         msg = lib().psvae_last_error().decode(errors='replace')
         raise RuntimeError(f'{name} failed with status {rc}: {msg}')
@@ -407,6 +414,16 @@ def pair_gather_bwd(g_feats, src, dst, pair_ptr, node_begin, node_end, g_h, g_z)
                                        ptr(src, torch.int32), ptr(dst, torch.int32), ptr(pair_ptr, torch.int32),
                                        ptr(node_begin, torch.int32), ptr(node_end, torch.int32), pgh, ldgh,
                                        pgz, ldgz, _stream()), 'psvae_pair_gather_bwd')
+
+
+def pair_combine_fwd(a, b, c, src, dst, graph, out, relu=True):
+    pa, lda = _rows(a)
+    pb, ldb = _rows(b)
+    pc, ldc = _rows(c)
+    po, ldo = _rows(out)
+    _check(lib().psvae_pair_combine_fwd(src.numel(), out.shape[1], pa, lda, pb, ldb, pc, ldc, ptr(src, torch.int32),
+                                        ptr(dst, torch.int32), ptr(graph, torch.int32), 1 if relu else 0, po, ldo,
+                                        _stream()), 'psvae_pair_combine_fwd')
 
 
 def link_ce_fwd(hid, W, b, golden, logits, dlogits, loss, n_correct):

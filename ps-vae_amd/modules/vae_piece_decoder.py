@@ -84,9 +84,28 @@ class VAEPieceDecoder(nn.Module):
     def link_logits(self, node_embedding, z_vecs, pairs, golden=None):
         """:99-110 (+ :115 when `golden` is given).  node_embedding [V,H] in the node ids the
         pair list uses.  Returns (logits, loss or None, n_correct or None)."""
-        feats = ops.pair_gather(node_embedding, z_vecs, pairs)
         mlp, last = self.edge_predictor[0], self.edge_predictor[1]
         seq = mlp.seq
+        H, L = node_embedding.shape[-1], z_vecs.shape[-1]
+        split_first = (golden is None and not torch.is_grad_enabled() and isinstance(seq, nn.Sequential)
+                       and len(seq) >= 4 and isinstance(seq[0], nn.Linear) and isinstance(seq[1], nn.ReLU)
+                       and isinstance(seq[-1], nn.Linear) and seq[0].bias is not None
+                       and seq[0].in_features == 2 * H + L and seq[0].out_features % 4 == 0 and H % 4 == 0)
+        if split_first:
+            # Inference over ALL candidate pairs (pairs >> atoms): the first layer's weight is cut at
+            # the [h_src | h_dst | z] blocks and applied once per atom / per molecule; per pair only
+            # a gather-add-ReLU remains, and the [P, 2H+L] feature rows are never formed.
+            first = seq[0]
+            w = first.weight
+            hu = ops.linear(node_embedding, w[:, :H])
+            hv = ops.linear(node_embedding, w[:, H:2 * H])
+            hz = ops.linear(z_vecs, w[:, 2 * H:], first.bias)
+            hid = torch.empty(len(pairs), first.out_features, dtype=torch.float32, device=w.device)
+            hip.pair_combine_fwd(hu, hv, hz, pairs.src, pairs.dst, pairs.graph, hid, relu=True)
+            hid = run_sequential(seq[2:-1], hid)
+            weight, bias = ops.affine_merge(last.weight, last.bias, seq[-1].weight, seq[-1].bias)
+            return ops.linear(hid, weight, bias), None, None
+        feats = ops.pair_gather(node_embedding, z_vecs, pairs)
         if isinstance(seq, nn.Sequential) and len(seq) > 1 and isinstance(seq[-1], nn.Linear):
             # No activation sits between the MLP's output layer and the class layer, so the
             # two are one affine map: W = W_last W_out, b = W_last b_out + b_last.  The wide
@@ -205,7 +224,7 @@ class VAEPieceDecoder(nn.Module):
         is one GRU cell over all still-active molecules (two GEMMs + the fused gate kernel),
         the vocabulary projection, the pad / first-step end masks, softmax(logits / T) and one
         draw per molecule.  The draw is the inverse-CDF form of torch.multinomial(probs, 1):
-        piece = first index whose cumulative probability reaches uniforms[b, t] (uniforms
+        piece = first index whose cumulative probability exceeds uniforms[b, t] x total (uniforms
         [B, max_pos] in [0,1), drawn here when None).  A molecule stops after the end token,
         when its atom count exceeds max_atom_num or at max_pos pieces, and its last sampled
         piece is dropped (:154-158).  Returns (piece_ids [B, max_pos-ish] padded with pad_idx,
@@ -237,6 +256,7 @@ class VAEPieceDecoder(nn.Module):
         atoms = torch.zeros(B, dtype=torch.int64, device=dev)
         active = torch.ones(B, dtype=torch.bool, device=dev)
         V = tok.num_piece_type()
+        col_ids = torch.arange(V, device=dev)[None, :]
         for t in range(max_pos):
             emb = self.piece_embedding(cur).contiguous()
             hip.gemm(B, 3 * H, E, emb, E, 1, w_ih, 1, E, gi, 3 * H, bias=rnn.bias_ih_l0)
@@ -247,7 +267,12 @@ class VAEPieceDecoder(nn.Module):
             if t == 0:
                 logits[:, end] = float('-inf')
             probs = torch.softmax(logits / temperature, dim=-1)
-            idx = (torch.cumsum(probs, dim=-1) < uniforms[:, t:t + 1]).sum(dim=-1).clamp(max=V - 1)
+            # first index whose cumulative probability exceeds u * total, never beyond the last
+            # entry of positive probability: an entry of probability zero (pad, the end token at
+            # t == 0) cannot be drawn, as with torch.multinomial
+            cdf = torch.cumsum(probs, dim=-1)
+            last = ((probs > 0) * col_ids).max(dim=-1).values
+            idx = torch.minimum((cdf <= uniforms[:, t:t + 1] * cdf[:, -1:]).sum(dim=-1), last)
             idx = torch.where(active, idx, torch.full_like(idx, pad))
             out[:, t] = idx
             length += active
@@ -360,8 +385,106 @@ class VAEPieceDecoder(nn.Module):
                            accepted, block, keep_atom, status)
         return {'accepted': accepted.bool(), 'block': block, 'keep_atom': keep_atom.bool(), 'status': status}
 
+    @torch.no_grad()
+    def expand_pieces(self, piece_ids, lengths, fragments=None):
+        """Sampled pieces -> the flat fragment graph of every molecule (:160-200 for a batch):
+        atom types, piece id and position (+1, as :183) of every atom, the in-piece bonds as a
+        CSR and the fragment index of every atom, all gathered from the vocabulary's fragment
+        table on the device (no per-molecule Python).  piece_ids [B,T] padded, lengths [B].
+        Returns a dict: x, x_pieces, x_pos, block0 [V]; node_off [B+1]; n_blocks [B]; csr_in."""
+        dev = self.W_mean.weight.device
+        table = (fragments or self.tokenizer.fragment_table()).on(dev)
+        i64 = torch.int64
+        piece_ids, lengths = piece_ids.to(dev), lengths.to(dev).to(i64)
+        B, T = piece_ids.shape
+        valid = torch.arange(T, device=dev)[None, :] < lengths[:, None]
+        mol_of_piece, pos_of_piece = valid.nonzero(as_tuple=True)            # row-major: molecule, then position
+        pid = piece_ids[valid].to(i64)
+        a0, e0 = table['atom_off'].to(i64), table['edge_off'].to(i64)
+        na, ne = a0[pid + 1] - a0[pid], e0[pid + 1] - e0[pid]
+        V, E = int(na.sum().item()), int(ne.sum().item())
+        piece_atom_base = torch.cumsum(na, 0) - na                            # first flat atom of each piece instance
+        piece_edge_base = torch.cumsum(ne, 0) - ne
+        inst = torch.repeat_interleave(torch.arange(pid.numel(), device=dev), na, output_size=V)
+        local = torch.arange(V, device=dev) - piece_atom_base[inst]
+        x = table['atom_type'].to(i64)[a0[pid][inst] + local]
+        x_pieces, block0 = pid[inst], pos_of_piece[inst]
+        atoms_per_mol = torch.zeros(B, dtype=i64, device=dev).index_add_(0, mol_of_piece, na)
+        node_off = torch.zeros(B + 1, dtype=i64, device=dev)
+        node_off[1:] = torch.cumsum(atoms_per_mol, 0)
+        einst = torch.repeat_interleave(torch.arange(pid.numel(), device=dev), ne, output_size=E)
+        elocal = torch.arange(E, device=dev) - piece_edge_base[einst]
+        eidx = e0[pid][einst] + elocal
+        src = piece_atom_base[einst] + table['edge_src'].to(i64)[eidx]
+        dst = piece_atom_base[einst] + table['edge_dst'].to(i64)[eidx]
+        row_ptr = torch.zeros(V + 1, dtype=i64, device=dev)
+        row_ptr[1:] = torch.cumsum(torch.bincount(src, minlength=V), 0)       # edges are already sorted by source
+        csr_in = ops.Csr(row_ptr.to(torch.int32), dst.to(torch.int32).contiguous(),
+                         table['edge_cls'][eidx].contiguous())
+        return {'x': x, 'x_pieces': x_pieces, 'x_pos': block0 + 1, 'block0': block0, 'node_off': node_off,
+                'n_blocks': lengths, 'csr_in': csr_in}
+
+    @torch.no_grad()
+    def inference_batch(self, z, max_atom_num, add_edge_th, temperature, uniforms=None, fragments=None):
+        """`inference` (:128-270) for a batch of latents without its RDKit calls: sample the
+        pieces, expand them into fragment graphs, predict the links between all cross-fragment
+        atom pairs, add bonds greedily under the valence / ring-size rules and keep the largest
+        connected block.  Returns (molecules, aux): molecules[b] = {'atoms': [chemical-vocabulary
+        index], 'bonds': [(begin, end, bond index)]} with the dropped atoms removed and the rest
+        renumbered (what the reference hands to Chem.SanitizeMol / Kekulize at :272-273, which
+        stay with RDKit); aux holds the device-side intermediate results."""
+        piece_ids, lengths = self.sample_pieces_batch(z, max_atom_num, temperature, uniforms=uniforms)
+        g = self.expand_pieces(piece_ids, lengths, fragments)
+        dev = g['x'].device
+        B = lengths.numel()
+        links = self.infer_links_batch(z, g['x'], g['x_pieces'], g['x_pos'], g['node_off'], g['csr_in'], g['block0'],
+                                       add_edge_th)
+        asm = self.assemble_links_batch(links, g['x'], g['node_off'], g['csr_in'], g['block0'], g['n_blocks'])
+        # packaging on the host: kept atoms renumbered, in-piece bonds (one direction) + accepted links
+        keep = asm['keep_atom']
+        node_off = g['node_off']
+        new_id = torch.cumsum(keep.to(torch.int64), 0) - 1
+        mol_of_atom = torch.repeat_interleave(torch.arange(B, device=dev), node_off[1:] - node_off[:-1],
+                                              output_size=keep.numel())
+        kept_before = torch.zeros(B + 1, dtype=torch.int64, device=dev)
+        kept_before[1:] = torch.cumsum(torch.zeros(B, dtype=torch.int64, device=dev).index_add_(
+            0, mol_of_atom, keep.to(torch.int64)), 0)
+        csr = g['csr_in']
+        V = keep.numel()
+        src = torch.repeat_interleave(torch.arange(V, device=dev),
+                                      (csr.row_ptr[1:] - csr.row_ptr[:-1]).to(torch.int64), output_size=csr.col.numel())
+        dst = csr.col.to(torch.int64)
+        one_dir = src < dst
+        b_src, b_dst, b_cls = src[one_dir], dst[one_dir], csr.cls[one_dir].to(torch.int64)
+        order = links['order']
+        acc = asm['accepted']
+        l_mol = links['graph'][order][acc]
+        l_src = node_off[l_mol] + links['m'][order][acc]
+        l_dst = node_off[l_mol] + links['n'][order][acc]
+        l_cls = links['etype'][order][acc]
+        all_src, all_dst = torch.cat([b_src, l_src]), torch.cat([b_dst, l_dst])
+        all_cls = torch.cat([b_cls, l_cls])
+        ok = keep[all_src] & keep[all_dst]
+        all_src, all_dst, all_cls = all_src[ok], all_dst[ok], all_cls[ok]
+        bond_mol = mol_of_atom[all_src]
+        perm = torch.argsort(bond_mol, stable=True)
+        bond_mol = bond_mol[perm]
+        base = kept_before[bond_mol]
+        bonds = torch.stack([new_id[all_src[perm]] - base, new_id[all_dst[perm]] - base, all_cls[perm]], 1).cpu().numpy()
+        bond_cnt = torch.bincount(bond_mol, minlength=B).cpu().numpy()
+        atoms = g['x'][keep].cpu().numpy()
+        atom_cnt = (kept_before[1:] - kept_before[:-1]).cpu().numpy()
+        mols, a, e = [], 0, 0
+        for b in range(B):
+            mols.append({'atoms': atoms[a:a + atom_cnt[b]].tolist(),
+                         'bonds': [tuple(int(v) for v in row) for row in bonds[e:e + bond_cnt[b]]]})
+            a += atom_cnt[b]
+            e += bond_cnt[b]
+        aux = dict(piece_ids=piece_ids, lengths=lengths, graph=g, links=links, assembly=asm)
+        return mols, aux
+
     def inference(self, z, max_atom_num, add_edge_th, temperature):
-        raise NotImplementedError(
-            'molecule assembly needs RDKit (piece SMILES -> atoms, valence / cycle checks, sanitisation: '
-            'src/modules/vae_piece_decoder.py:160-201, 243-274) and is outside the accelerated path; '
-            'its link-prediction slice is VAEPieceDecoder.infer_links')
+        """:128-274 for one latent; returns the generated molecule as an atoms / bonds dict
+        (the reference returns an rdkit Mol after SanitizeMol / Kekulize, which need RDKit)."""
+        mols, _ = self.inference_batch(z.reshape(1, -1), max_atom_num, add_edge_th, temperature)
+        return mols[0]

@@ -161,7 +161,15 @@ class PSVAEModel(nn.Module):
         return self.decoder.inference(z, max_atom_num, add_edge_th, temperature)
 
     def inference_batch_z(self, zs, max_atom_num, add_edge_th, temperature, constraint_mol=None):
-        return [self.inference_single_z(z, max_atom_num, add_edge_th, temperature) for z in zs]
+        """The reference loops inference_single_z over the latents (:139-141, "not accelerating,
+        just a loop"); here the whole batch goes through sampling, link prediction and greedy
+        assembly at once.  Returns one atoms / bonds dict per latent (see
+        VAEPieceDecoder.inference_batch)."""
+        if constraint_mol is not None:
+            raise NotImplementedError('constrained generation (inference_constraint) is outside the accelerated path')
+        zs = torch.stack(list(zs)) if not torch.is_tensor(zs) else zs
+        mols, _ = self.decoder.inference_batch(zs, max_atom_num, add_edge_th, temperature)
+        return mols
 
     def predict_props(self, z):
         props = self.predictor(z)

@@ -16,6 +16,10 @@ Files written:
                        re-creates them from the seed)
   beta_table.npz       cal_beta over global steps 0..6000
   infer_links.npz      inference link-prediction slice for fragment sets
+  assemble_checks.npz  known answers of valence_check / cycle_check / shortest_path_len
+  inference_cases.npz  VAEPieceDecoder.inference end to end (sampling, link prediction, greedy
+                       assembly) on graph stand-ins for the RDKit objects: latents, uniforms,
+                       final atoms and bonds
 """
 import json
 import os
@@ -142,6 +146,9 @@ def run_ref_model(model, batch, eps, return_accu=False):
         torch.randn_like = real
 
 
+SAMPLE_STRIDE = 97   # element-wise sample of the default-width tensors (every 97th element)
+
+
 def make_model(fname, args, step1, seed, store_weights):
     config = ref_config(args)
     torch.manual_seed(seed)
@@ -204,6 +211,9 @@ def make_model(fname, args, step1, seed, store_weights):
         if store_weights:
             out[f'grad/{k}'] = p.grad.numpy().copy()
         out[f'gradnorm/{k}'] = p.grad.norm().numpy()
+        if not store_weights:     # a strided element-wise sample pins the wide tensors directly
+            out[f'gradsample/{k}'] = p.grad.reshape(-1)[::SAMPLE_STRIDE].numpy().copy()
+            out[f'gradmax/{k}'] = p.grad.abs().max().numpy()
     out['no_grad_params'] = np.asarray(no_grad)
     opt = torch.optim.Adam(model.parameters(), lr=config['lr'])
     total_norm = torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
@@ -215,6 +225,7 @@ def make_model(fname, args, step1, seed, store_weights):
     else:
         for k, v in model.state_dict().items():
             out[f'after_step_norm/{k}'] = v.norm().numpy()
+            out[f'after_step_sample/{k}'] = v.reshape(-1)[::SAMPLE_STRIDE].numpy().copy()
     np.savez_compressed(os.path.join(HERE, fname), **out)
     print(fname, 'losses', {k: float(out[k]) for k in out if k.startswith('loss/')},
           'no-grad params', no_grad, 'P', len(batch['golden_edge']))
@@ -402,9 +413,198 @@ def make_assemble_checks():
           'cycle checks pass;', int((c_len == 0).sum()), 'unreachable')
 
 
+class _FragBond:
+    def __init__(self, a, b, order, bond_types):
+        self.a, self.b, self.t = a, b, bond_types[order]
+
+    def GetBeginAtomIdx(self):
+        return self.a
+
+    def GetEndAtomIdx(self):
+        return self.b
+
+    def GetBondType(self):
+        return self.t
+
+
+class _FragAtom:
+    def __init__(self, symbol):
+        self.symbol = symbol
+
+    def GetSymbol(self):
+        return self.symbol
+
+
+class _FragMol:
+    """What VAEPieceDecoder.inference asks of smiles2molecule(piece) (:168-200): atoms in SMILES
+    order with their symbols, bonds with begin / end / type."""
+
+    def __init__(self, symbols, bonds, bond_types):
+        self.symbols = symbols
+        self.bonds = [_FragBond(a, b, o, bond_types) for a, b, o in bonds]
+
+    def GetNumAtoms(self):
+        return len(self.symbols)
+
+    def GetAtomWithIdx(self, i):
+        return _FragAtom(self.symbols[i])
+
+    def GetBonds(self):
+        return self.bonds
+
+
+class _GraphRWMol:
+    """The RWMol calls of VAEPieceDecoder.inference (:166, 186, 201, 254, 270-271) and of
+    cycle_check (GetAtomWithIdx(i).GetNeighbors()) on a plain atom / bond list."""
+
+    def __init__(self):
+        self.symbols, self.bonds = [], []
+
+    def AddAtom(self, atom):
+        self.symbols.append(atom.symbol)
+        return len(self.symbols) - 1
+
+    def AddBond(self, a, b, t):
+        self.bonds.append([int(a), int(b), t])
+
+    @property
+    def adj(self):
+        adj = [[] for _ in self.symbols]
+        for a, b, _ in self.bonds:
+            adj[a].append(b), adj[b].append(a)
+        return adj
+
+    def GetAtomWithIdx(self, i):
+        return _AdjAtom(_AdjMol(self.adj), i)
+
+    def RemoveAtom(self, aid):
+        del self.symbols[aid]
+        self.bonds = [[a - (a > aid), b - (b > aid), t] for a, b, t in self.bonds if a != aid and b != aid]
+
+    def GetMol(self):
+        return self
+
+
+def make_inference():
+    """The reference's own VAEPieceDecoder.inference (src/modules/vae_piece_decoder.py:128-274),
+    called unmodified, with RDKit replaced by graph containers: piece SMILES -> atoms / bonds
+    through ps_vae_amd.utils.fragments.parse_piece_smiles (the stand-in for
+    smiles2molecule(kekulize=True) on kekulised pieces), an atom / bond list behind Chem.RWMol,
+    SanitizeMol / Kekulize as no-ops.  torch.multinomial is replaced by the inverse-CDF draw from
+    recorded uniforms (first index whose cumulative probability exceeds u * total), so the
+    sampling loop, the link-prediction slice, the greedy bond loop with its valence / cycle
+    checks, the block merging and the largest-block selection all run as the reference wrote them.
+    Cases whose draws or confidences sit within 1e-3 / 1e-4 of a decision boundary are skipped, so
+    that an fp32 implementation that rounds differently takes the same decisions."""
+    import modules.vae_piece_decoder as vpd
+    import torch.nn.functional as F
+    from ps_vae_amd.utils.fragments import parse_piece_smiles
+    from ps_vae_amd.utils.tokenizer import synthetic_pieces
+    from rdkit import Chem
+
+    pieces = synthetic_pieces(300)
+    tok_gen = rh.RefTokenizer(ns.GeneralVocab, 300)
+    tok_gen.idx2piece = pieces + ['<pad>', '<s>']
+    tok_gen.piece2idx = {p: i for i, p in enumerate(tok_gen.idx2piece)}
+    bond_types = [None, Chem.BondType.SINGLE, Chem.BondType.DOUBLE, Chem.BondType.TRIPLE]
+    vpd.smiles2molecule = lambda smi, kekulize=True: _FragMol(*parse_piece_smiles(smi), bond_types)
+    Chem.RWMol = _GraphRWMol
+    Chem.Atom = _FragAtom
+    Chem.SanitizeMol = lambda mol: None
+    Chem.Kekulize = lambda mol: None
+
+    args = args_namespace(node_hidden_dim=36, graph_embedding_dim=40, latent_dim=8, atom_embedding_dim=6,
+                          piece_embedding_dim=12, pos_embedding_dim=6, piece_hidden_dim=20, predictor_hidden_dim=16)
+    config = ref_config(args)
+    config['vae_piece_decoder']['tokenizer'] = tok_gen
+    torch.manual_seed(9)
+    model = ns.PSVAEModel(config, tok_gen)
+    dec = model.decoder
+    with torch.no_grad():   # an untrained head predicts one class with conf ~0.28 everywhere: spread it
+        for lin, k in ((dec.edge_predictor[0].seq[0], 6.0), (dec.edge_predictor[0].seq[2], 4.0),
+                       (dec.edge_predictor[0].seq[4], 4.0), (dec.edge_predictor[1], 4.0)):
+            lin.weight.mul_(k)
+            lin.bias.uniform_(-0.5, 0.5)
+        dec.graph_embedding.node_trans.weight.mul_(3.0)
+        dec.to_vocab.weight.mul_(3.0)       # a less uniform piece distribution
+    out = {'pieces': np.asarray(tok_gen.idx2piece)}
+    for k, v in model.state_dict().items():
+        out[f'state/{k}'] = v.numpy().copy()
+
+    th, max_atoms, temperature = 0.5, 20, 1.0
+    state = {}
+
+    def fake_multinomial(probs, num_samples=1):
+        u = state['u'][state['t']]
+        state['t'] += 1
+        cdf = torch.cumsum(probs, 0)
+        total = cdf[-1]
+        last = int((probs > 0).nonzero().max())
+        pid = min(int((cdf <= u * total).sum()), last)
+        lo = float(cdf[pid - 1]) if pid > 0 else 0.0
+        state['margin'] = min(state['margin'], float(u * total) - lo, float(cdf[pid]) - float(u * total))
+        return torch.tensor([pid])
+
+    real_multinomial, real_max = torch.multinomial, torch.max
+    conf_seen = {}
+
+    def spy_max(t, *a, **k):        # the (confidence, type) pair of :236
+        res = real_max(t, *a, **k)
+        if a or k:
+            conf_seen['conf'], conf_seen['type'] = res[0].detach().clone(), res[1].detach().clone()
+        return res
+
+    rng = np.random.default_rng(33)
+    gen = torch.Generator().manual_seed(34)
+    kept = 0
+    torch.multinomial, torch.max = fake_multinomial, spy_max
+    try:
+        for trial in range(4000):
+            z = torch.randn(args.latent_dim, generator=gen)
+            u = rng.random(50).astype(np.float32)
+            state.update(u=torch.from_numpy(u), t=0, margin=1.0)
+            conf_seen.clear()
+            with torch.no_grad():
+                mol = dec.inference(z, max_atoms, th, temperature)
+            if state['margin'] < 1e-3:
+                continue
+            if conf_seen:
+                c = conf_seen['conf'].numpy()
+                keep = c[(c >= th) & (conf_seen['type'].numpy() != 0)]
+                srt = np.sort(keep)
+                if np.any(np.abs(c - th) < 1e-4) or (len(srt) > 1 and np.min(np.diff(srt)) < 1e-5):
+                    continue
+            vocab = tok_gen.chem_vocab
+            pre = f'case{kept}/'
+            out[pre + 'z'] = z.numpy()
+            out[pre + 'uniforms'] = u
+            out[pre + 'draws'] = np.int64(state['t'])
+            out[pre + 'atoms'] = np.asarray([vocab.atom_to_idx(s) for s in mol.symbols], dtype=np.int64)
+            out[pre + 'bonds'] = np.asarray([[a, b, vocab.bond_to_idx(t)] for a, b, t in mol.bonds],
+                                            dtype=np.int64).reshape(-1, 3)
+            kept += 1
+            if kept == 48:
+                break
+    finally:
+        torch.multinomial, torch.max = real_multinomial, real_max
+    out['num_cases'] = np.int64(kept)
+    out['add_edge_th'], out['max_atom_num'], out['temperature'] = np.float64(th), np.int64(max_atoms), np.float64(temperature)
+    np.savez_compressed(os.path.join(HERE, 'inference_cases.npz'), **out)
+    sizes = [len(out[f'case{i}/atoms']) for i in range(kept)]
+    nb = [len(out[f'case{i}/bonds']) for i in range(kept)]
+    print(f'inference_cases: {kept} cases, atoms {min(sizes)}..{max(sizes)}, bonds {min(nb)}..{max(nb)}')
+
+
 if __name__ == '__main__':
     if sys.argv[1:] == ['assemble']:
         make_assemble_checks()
+        sys.exit(0)
+    if sys.argv[1:] == ['inference']:
+        make_inference()
+        sys.exit(0)
+    if sys.argv[1:] == ['default']:
+        make_model('model_default.npz', args_namespace(), synthetic_step1(8, seed=41, shape='zinc'),
+                   seed=2021, store_weights=False)
         sys.exit(0)
     make_collate()
     small = args_namespace(node_hidden_dim=36, graph_embedding_dim=40, latent_dim=8, atom_embedding_dim=6,
@@ -417,3 +617,4 @@ if __name__ == '__main__':
     make_beta()
     make_infer()
     make_assemble_checks()
+    make_inference()

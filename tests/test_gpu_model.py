@@ -167,6 +167,19 @@ def test_default_width_model_against_reference_golden(tokenizer):
             assert k in set(gold['no_grad_params'].tolist())
             continue
         np.testing.assert_allclose(p.grad.norm().item(), gold[f'gradnorm/{k}'], rtol=1e-4, err_msg=k)
+        # element-wise against the reference itself: every 97th entry of every gradient at the
+        # widths the kernels are tuned for, within 2e-5 of the tensor's largest entry
+        got = p.grad.reshape(-1)[::97].cpu().numpy()
+        err = np.abs(got - gold[f'gradsample/{k}']).max()
+        assert err <= 2e-5 * float(gold[f'gradmax/{k}']), f'{k}: {err:.3e} vs max {float(gold[f"gradmax/{k}"]):.3e}'
+    (opt,), _ = model.configure_optimizers()          # also packs the gradients just produced
+    opt.max_norm = 10.0
+    opt.step()
+    np.testing.assert_allclose(opt.grad_norm.item(), gold['grad_total_norm'], rtol=1e-5)
+    for k, v in model.state_dict().items():
+        want = gold[f'after_step_sample/{k}']
+        got = v.reshape(-1)[::97].cpu().numpy()
+        assert np.abs(got - want).max() <= 2e-5 * max(np.abs(want).max(), 1e-30), f'after step {k}'
 
 
 def test_default_width_batch_256_against_oracle(tokenizer):
@@ -182,8 +195,8 @@ def test_default_width_batch_256_against_oracle(tokenizer):
     ReLU kinks: with ~16 M ReLU inputs in this batch a few lie within fp32 rounding of zero,
     and an implementation that rounds differently takes the other side of the kink (the loss
     is not differentiable there).  The test counts the ReLU outputs whose sign differs from
-    the float64 oracle's; they must be at most 8, and only when there is such a flip is the
-    bound on the gradients relaxed to 2e-3 of the tensor's largest entry."""
+    the float64 oracle's (at most 8) and compares the gradients with the float64 oracle
+    re-evaluated under the GPU's own ReLU decisions, so the bound is NOT relaxed for a flip."""
     import copy
     from ps_vae_amd import ops as hip_ops
     from ps_vae_amd.data.collate import collate_packed
@@ -243,20 +256,48 @@ def test_default_width_batch_256_against_oracle(tokenizer):
         assert a.shape == b.shape
         flips += ((a.cpu() > 0) != (b > 0)).sum().item()
     assert flips <= 8, f'{flips} ReLU outputs on the other side of the kink'
-    kink_bound = 2e-3 if flips else 0.0
 
-    refp, refp64 = dict(ref.named_parameters()), dict(ref64.named_parameters())
+    # The yardstick for the gradients: the float64 oracle evaluated with the GPU's own ReLU
+    # decisions forced (every ReLU output = input x [GPU output > 0]).  Where the GPU took the
+    # same side of every kink this IS the float64 oracle; where a pre-activation within fp32
+    # rounding of zero fell on the other side, it is the derivative of the function the GPU
+    # actually evaluated - so a gradient error that is NOT explained by such a flip still fails.
+    ref64f = copy.deepcopy(ref).double()
+    for q in ref64f.parameters():
+        q.grad = None
+    masks = iter([(a > 0).cpu() for a in relu_gpu])
+
+    def force(mod, inp, out):
+        x, m = inp[0], next(masks)
+        if x.shape[0] == real.numel():
+            full = x > 0
+            full[real] = m
+        else:
+            full = m
+        return x * full
+    hooks = [m.register_forward_hook(force) for m in ref64f.modules() if isinstance(m, torch.nn.ReLU)]
+    plf, (recf, _, _, klf) = ref64f(tb, eps.double())
+    for h in hooks:
+        h.remove()
+    ref64f.weighted_loss(plf, recf, klf).backward()
+
+    refp, refp64, refp64f = dict(ref.named_parameters()), dict(ref64.named_parameters()), dict(ref64f.named_parameters())
+    worst = (0.0, '')
     for k, p in model.named_parameters():
         if refp[k].grad is None:
             assert p.grad is None, k
             continue
-        g64 = refp64[k].grad
+        g64, g64f = refp64[k].grad, refp64f[k].grad
         scale = g64.abs().max().item()
-        err_gpu = (p.grad.cpu().double() - g64).abs().max().item()
+        err_gpu = (p.grad.cpu().double() - g64f).abs().max().item()
         err_cpu = (refp[k].grad.double() - g64).abs().max().item()
-        assert err_gpu <= max(1e-5 * scale, 2.0 * err_cpu, kink_bound * scale), \
-            f'grad {k}: GPU {err_gpu / scale:.2e}, fp32 CPU oracle {err_cpu / scale:.2e} (relative to float64), ' \
-            f'{flips} ReLU flips'
+        worst = max(worst, (err_gpu / scale, k))
+        # 1e-5 of the tensor's largest entry, or - on the few tensors where fp32 summation order
+        # alone moves the fp32 CPU oracle further than that from float64 - twice that distance
+        assert err_gpu <= max(1e-5 * scale, 2.0 * err_cpu), \
+            f'grad {k}: GPU {err_gpu / scale:.2e} of the largest entry from the float64 oracle under the GPU\'s ' \
+            f'ReLU decisions; fp32 CPU oracle {err_cpu / scale:.2e} from the plain float64 oracle; {flips} ReLU flips'
+    print(f'{flips} ReLU flips; largest GPU gradient error {worst[0]:.2e} ({worst[1]})')
 
 
 def test_loss_curve_follows_the_oracle_over_30_steps(tokenizer):
