@@ -122,6 +122,15 @@ int psvae_embed_atom_bwd(int V, const int32_t *x, const int32_t *xp, const int32
 int psvae_embed_atom_onehot(int V, const int32_t *x, const int32_t *xp, const int32_t *xq,
                             int n_atom, int n_piece, int n_pos, float *out, int ld, void *stream);
 
+/* A single embedding table (the piece embedding of the language model,
+ * src/modules/vae_piece_decoder.py:26,78): out[v] = table[ids[v]], rows of D floats (D % 4 == 0),
+ * ids outside [0, n_rows) clamped into it.  psvae_onehot_f32 writes the indicator rows
+ * out[v][j] = (j == ids[v]), j < ld (ld % 4 == 0, ld >= n_rows): out^T g, one psvae_gemm_f32 call,
+ * is the table gradient, summed in a fixed order. */
+int psvae_embedding_fwd(int V, int D, int n_rows, const int32_t *ids, const float *table, float *out,
+                        void *stream);
+int psvae_onehot_f32(int V, const int32_t *ids, float *out, int ld, void *stream);
+
 /* ------------------------------------------------------------------------------------
  * GINE aggregation, the message/aggregate half of torch_geometric.nn.GINEConv as called at
  * src/modules/encoder.py:58 with eps = 0:
@@ -232,6 +241,22 @@ int psvae_gru_cell_fwd(int B, int H, const float *gi, const float *gh, const flo
 int psvae_gru_cell_bwd(int B, int H, const float *gates, const float *gh, const float *h_prev,
                        const float *dh, const float *dh_extra, float *dgi, float *dgh,
                        float *dh_prev, void *stream);
+
+/* The whole recurrence of that GRU in one launch per direction (teacher-forced training,
+ * src/modules/vae_piece_decoder.py:85-89): a workgroup owns 16 batch rows and walks all T steps.
+ * gi [T,B,3H] = x_t W_ih^T + b_ih for every step (one psvae_gemm_f32 call), h0 [B,H],
+ * w_hh [3H,H] (16-byte aligned), b_hh [3H] or NULL.  Writes hall [T+1,B,H] (hall[0] = h0) and,
+ * unless NULL, what the backward needs: gates [T,B,3H] = (r, z, n) and ghn [T,B,H] = W_hn h + b_hn.
+ * Backward: g_out [T,B,H] = dL/d hall[1..T], w_hh_t [H,3H] = W_hh transposed; writes
+ * dgi, dgh [T,B,3H] (gradients of the two pre-activation inputs of every step; the weight and
+ * bias gradients are products over them) and dh0 [B,H].  H % 4 == 0 and H <= PSVAE_GRU_SEQ_MAX_H
+ * (PSVAE_ETOOLARGE otherwise: use the per-step kernels above). */
+#define PSVAE_GRU_SEQ_MAX_H 256
+int psvae_gru_seq_fwd(int T, int B, int H, const float *gi, const float *h0, const float *w_hh,
+                      const float *b_hh, float *hall, float *gates, float *ghn, void *stream);
+int psvae_gru_seq_bwd(int T, int B, int H, const float *gates, const float *ghn, const float *hall,
+                      const float *g_out, const float *w_hh_t, float *dgi, float *dgh, float *dh0,
+                      void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Link predictor input (src/modules/vae_piece_decoder.py:99-109) without the [B,N,N,*]

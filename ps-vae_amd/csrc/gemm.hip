@@ -28,6 +28,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 namespace {
 
 constexpr int THREADS = 256;
+// Tuning constants of the panel kernel (the -D overrides exist for A/B builds only).
+#ifndef PSVAE_PANEL_BK
+#define PSVAE_PANEL_BK 32      // k-tile depth of the panels up to 192 columns wide
+#endif
+#ifndef PSVAE_PANEL_OCC
+#define PSVAE_PANEL_OCC 3      // workgroups per CU the register budget of those panels is set for
+#endif
+#ifndef PSVAE_PANEL_NBUF
+#define PSVAE_PANEL_NBUF 1     // LDS stages of the operand tiles
+#endif
 
 struct GemmArgs {
     int M, N, K;
@@ -173,13 +183,16 @@ struct TileLoader {
 // WN = 1: the 4 waves stack along M (128-row panel, 32*TN columns).  WN = 2: a 2 x 2 wave grid
 // (64 rows x 64*TN columns), for products whose M fits 64-row panels with less padding.
 template <int TN, int BK, bool A_KC, bool B_KC, bool MASK, bool ONES, int WN = 1>
-__global__ __launch_bounds__(THREADS, (MASK || WN > 1 || TN > 5) ? 2 : 3) void gemm_panel_kernel(GemmArgs g) {
+__global__ __launch_bounds__(THREADS, (MASK || WN > 1 || TN > 5) ? 2 : PSVAE_PANEL_OCC) void gemm_panel_kernel(GemmArgs g) {
     constexpr int WM = 4 / WN, BM = 32 * WM, BN = 32 * TN * WN;
     using LA = TileLoader<BM, BK, A_KC>;
     using LB = TileLoader<BN, BK, B_KC>;
     constexpr int A_FLOATS = BK * LA::STRIDE, B_FLOATS = BK * LB::STRIDE;
+    constexpr int STAGE_FLOATS = A_FLOATS + B_FLOATS;
+    // two LDS stages where two workgroups of them still fit a CU's 160 KiB
+    constexpr int NBUF = (PSVAE_PANEL_NBUF == 2 && 2 * STAGE_FLOATS * 4 <= 76 * 1024) ? 2 : 1;
     constexpr int EPI_STRIDE = 36, EPI_FLOATS = 4 * 32 * EPI_STRIDE;   // one 32x32 tile per wave
-    constexpr int LDS_FLOATS = A_FLOATS + B_FLOATS > EPI_FLOATS ? A_FLOATS + B_FLOATS : EPI_FLOATS;
+    constexpr int LDS_FLOATS = NBUF * STAGE_FLOATS > EPI_FLOATS ? NBUF * STAGE_FLOATS : EPI_FLOATS;
     __shared__ __align__(16) float smem[LDS_FLOATS];
     float *As = smem, *Bs = smem + A_FLOATS;
 
@@ -211,34 +224,36 @@ __global__ __launch_bounds__(THREADS, (MASK || WN > 1 || TN > 5) ? 2 : 3) void g
     const bool a_inside = m0 + BM <= g.M, b_inside = n0 + BN <= n_lim;
     const float *a_rd = As + lhi * LA::STRIDE + wave_m * 32 + l31;
     const float *b_rd = Bs + lhi * LB::STRIDE + wave_n * TN * 32 + l31;
-    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+
+    // registers -> LDS stage `buf` for the k-tile that starts at k0
+    auto stage = [&](int buf, int k0) {
+        float *as = As + buf * STAGE_FLOATS, *bs = Bs + buf * STAGE_FLOATS;
         if (k0 + BK <= k_end && a_inside)   // wave-uniform
-            LA::template store<MASK, false, true>(As, ra, rma, m0, k0, g.M, k_end, -1, tid);
+            LA::template store<MASK, false, true>(as, ra, rma, m0, k0, g.M, k_end, -1, tid);
         else
-            LA::template store<MASK, false>(As, ra, rma, m0, k0, g.M, k_end, -1, tid);
+            LA::template store<MASK, false>(as, ra, rma, m0, k0, g.M, k_end, -1, tid);
         if (k0 + BK <= k_end && b_inside)
-            LB::template store<false, ONES, true>(Bs, rb, rmb, n0, k0, n_lim, k_end, ones_x, tid);
+            LB::template store<false, ONES, true>(bs, rb, rmb, n0, k0, n_lim, k_end, ones_x, tid);
         else
-            LB::template store<false, ONES>(Bs, rb, rmb, n0, k0, n_lim, k_end, ones_x, tid);
-        __syncthreads();
-        if (k0 + BK < k_end) {
-            LA::template load<MASK>(ra, rma, g.A, g.amask, g.sa_m, g.sa_k, m0, k0 + BK, g.M, k_end, tid);
-            LB::template load<false>(rb, rmb, g.B, nullptr, g.sb_n, g.sb_k, n0, k0 + BK, n_lim, k_end, tid);
-        }
-        // operand registers for k-step s+1 are fetched from LDS while the MFMAs of step s run;
-        // the scheduling barriers keep the compiler from sinking the reads next to their use
-        float a_cur = a_rd[0], b_cur[TN];
+            LB::template store<false, ONES>(bs, rb, rmb, n0, k0, n_lim, k_end, ones_x, tid);
+    };
+    // the MFMAs of one k-tile from stage `buf`: operand registers for k-step s+1 are fetched from
+    // LDS while the MFMAs of step s run; the scheduling barriers keep the compiler from sinking the
+    // reads next to their use
+    auto multiply = [&](int buf, int k0) {
+        const float *ar = a_rd + buf * STAGE_FLOATS, *br = b_rd + buf * STAGE_FLOATS;
+        float a_cur = ar[0], b_cur[TN];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) b_cur[j] = b_rd[j * 32];
+        for (int j = 0; j < TN; ++j) b_cur[j] = br[j * 32];
         const int k_live = k_end - k0;   // the last k-tile of a chunk may be partly empty
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             if (kk > 0 && kk >= k_live) break;   // wave-uniform
             float a_nxt = 0.f, b_nxt[TN];
             if (kk + 2 < BK) {
-                a_nxt = a_rd[(kk + 2) * LA::STRIDE];
+                a_nxt = ar[(kk + 2) * LA::STRIDE];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) b_nxt[j] = b_rd[(kk + 2) * LB::STRIDE + j * 32];
+                for (int j = 0; j < TN; ++j) b_nxt[j] = br[(kk + 2) * LB::STRIDE + j * 32];
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -254,7 +269,37 @@ __global__ __launch_bounds__(THREADS, (MASK || WN > 1 || TN > 5) ? 2 : 3) void g
                 for (int j = 0; j < TN; ++j) b_cur[j] = b_nxt[j];
             }
         }
+    };
+    if constexpr (NBUF == 1) {
+        // one LDS stage: write it, barrier, request the next k-tile, multiply, barrier
+        for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+            stage(0, k0);
+            __syncthreads();
+            if (k0 + BK < k_end) {
+                LA::template load<MASK>(ra, rma, g.A, g.amask, g.sa_m, g.sa_k, m0, k0 + BK, g.M, k_end, tid);
+                LB::template load<false>(rb, rmb, g.B, nullptr, g.sb_n, g.sb_k, n0, k0 + BK, n_lim, k_end, tid);
+            }
+            multiply(0, k0);
+            __syncthreads();
+        }
+    } else {
+        // two LDS stages: the next k-tile is requested before the current one is multiplied and
+        // written to the other stage right after, so a k-tile costs ONE barrier and the staging
+        // stores of a wave run beside the other waves' MFMAs
+        if (k_begin < k_end) stage(0, k_begin);
         __syncthreads();
+        int cur = 0;
+        for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+            const bool more = k0 + BK < k_end;   // block-uniform
+            if (more) {
+                LA::template load<MASK>(ra, rma, g.A, g.amask, g.sa_m, g.sa_k, m0, k0 + BK, g.M, k_end, tid);
+                LB::template load<false>(rb, rmb, g.B, nullptr, g.sb_n, g.sb_k, n0, k0 + BK, n_lim, k_end, tid);
+            }
+            multiply(cur, k0);
+            if (more) stage(cur ^ 1, k0 + BK);
+            __syncthreads();
+            cur ^= 1;
+        }
     }
 
     // Epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) +
@@ -612,11 +657,14 @@ extern "C" int psvae_gemm_f32(int M, int N, int K, const float *A, const float *
     const bool a_vec = (a_kc ? (K % 4 == 0 && vec_ok(A, sa_m)) : (sa_m == 1 && M % 4 == 0 && vec_ok(A, sa_k))) &&
                        (amask == nullptr || psvae_aligned16(amask));
     const bool b_vec = b_kc ? (K % 4 == 0 && vec_ok(B, sb_n)) : (sb_n == 1 && N % 4 == 0 && vec_ok(B, sb_k));
-    const bool panel = a_vec && b_vec && (!rowsum || !b_kc) && M >= 32;
+    bool panel = a_vec && b_vec && (!rowsum || !b_kc) && M >= 32;
+    int nc = 1, bn = 32, tn = 1;
+    if (panel) panel_shape(g.n_ext, nc, bn, tn);
+#ifdef PSVAE_FAST_BUILD   // A/B builds instantiate the 160-column panels only: everything else goes generic
+    panel = panel && (tn == 5 || (!a_kc && !b_kc && prefer_2x2(M, g.n_ext)));
+#endif
 
     if (panel) {
-        int nc, bn, tn;
-        panel_shape(g.n_ext, nc, bn, tn);
         g.nt_m = psvae_cdiv(M, 128), g.nt_n = nc, g.bn = bn, g.wn = 1;
         if (!a_kc && !b_kc && prefer_2x2(M, g.n_ext)) {
             g.wn = 2, g.nt_m = psvae_cdiv(M, 64), g.nt_n = 1, g.bn = 320;
@@ -626,15 +674,17 @@ extern "C" int psvae_gemm_f32(int M, int N, int K, const float *A, const float *
         PSVAE_REQUIRE(blocks < (1ll << 31), PSVAE_ETOOLARGE, "psvae_gemm_f32: grid too large");
         dim3 grid((unsigned)blocks);
         switch (tn) {
-            case 1: launch_panel<1, 32>(g, a_kc, b_kc, grid, s); break;
-            case 2: launch_panel<2, 32>(g, a_kc, b_kc, grid, s); break;
-            case 3: launch_panel<3, 32>(g, a_kc, b_kc, grid, s); break;
-            case 4: launch_panel<4, 32>(g, a_kc, b_kc, grid, s); break;
-            case 5: launch_panel<5, 32>(g, a_kc, b_kc, grid, s); break;
-            case 6: launch_panel<6, 32>(g, a_kc, b_kc, grid, s); break;
+#ifndef PSVAE_FAST_BUILD
+            case 1: launch_panel<1, PSVAE_PANEL_BK>(g, a_kc, b_kc, grid, s); break;
+            case 2: launch_panel<2, PSVAE_PANEL_BK>(g, a_kc, b_kc, grid, s); break;
+            case 3: launch_panel<3, PSVAE_PANEL_BK>(g, a_kc, b_kc, grid, s); break;
+            case 4: launch_panel<4, PSVAE_PANEL_BK>(g, a_kc, b_kc, grid, s); break;
+            case 6: launch_panel<6, PSVAE_PANEL_BK>(g, a_kc, b_kc, grid, s); break;
             case 7: launch_panel<7, 16>(g, a_kc, b_kc, grid, s); break;
             case 10: launch_panel<10, 16>(g, a_kc, b_kc, grid, s); break;
-            default: launch_panel<11, 16>(g, a_kc, b_kc, grid, s); break;
+            case 11: launch_panel<11, 16>(g, a_kc, b_kc, grid, s); break;
+#endif
+            default: launch_panel<5, PSVAE_PANEL_BK>(g, a_kc, b_kc, grid, s); break;
         }
     } else {
         g.nt_m = psvae_cdiv(M, GB), g.nt_n = psvae_cdiv(g.n_ext, GB), g.bn = GB;

@@ -83,6 +83,31 @@ __global__ void embed_atom_onehot_kernel(int V, const int32_t *__restrict__ x, c
     }
 }
 
+// ---------------------------------------------------------------- plain embedding lookup
+// out[v] = table[ids[v]] (rows of D floats, D % 4 == 0); ids outside the table are clamped.
+__global__ void embedding_fwd_kernel(int V, int d4, int n_rows, const int32_t *__restrict__ ids,
+                                     const float4 *__restrict__ table, float4 *__restrict__ out) {
+    const long long total = (long long)V * d4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int v = (int)(i / d4), c = (int)(i - (long long)v * d4);
+        const int id = min(max(ids[v], 0), n_rows - 1);
+        out[i] = table[(long long)id * d4 + c];
+    }
+}
+
+// out[v][j] = (j == ids[v]) for j < ld (ld % 4 == 0): the indicator whose transpose times a
+// gradient gives the table gradient deterministically on the matrix cores.
+__global__ void onehot_kernel(int V, const int32_t *__restrict__ ids, float4 *__restrict__ out, int ld4) {
+    const long long total = (long long)V * ld4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int v = (int)(i / ld4), j = (int)(i - (long long)v * ld4) * 4;
+        const int a = ids[v];
+        out[i] = make_float4(j == a ? 1.f : 0.f, j + 1 == a ? 1.f : 0.f, j + 2 == a ? 1.f : 0.f, j + 3 == a ? 1.f : 0.f);
+    }
+}
+
 // ---------------------------------------------------------------- segment sum (embed_graph)
 __global__ void segment_sum_fwd_kernel(int cols, const float4 *__restrict__ x, int ldx4,
                                        const int32_t *__restrict__ seg_begin, const int32_t *__restrict__ seg_end,
@@ -588,6 +613,31 @@ extern "C" int psvae_embed_atom_onehot(int V, const int32_t *x, const int32_t *x
     hipLaunchKernelGGL(embed_atom_onehot_kernel, dim3(grid_for((long long)V * (ld / 4), 256, 16384)), dim3(256), 0,
                        (hipStream_t)stream, V, x, xp, xq, n_atom, n_piece, (float4 *)out, ld / 4);
     PSVAE_CHECK_LAUNCH("psvae_embed_atom_onehot");
+    return PSVAE_OK;
+}
+
+extern "C" int psvae_embedding_fwd(int V, int D, int n_rows, const int32_t *ids, const float *table, float *out,
+                                   void *stream) {
+    const char *fn = "psvae_embedding_fwd";
+    PSVAE_REQUIRE(V >= 0 && D > 0 && D % 4 == 0 && n_rows > 0, PSVAE_EINVAL, "%s: bad sizes V=%d D=%d rows=%d", fn, V, D,
+                  n_rows);
+    if (V == 0) return PSVAE_OK;
+    PSVAE_REQUIRE(ids && table && out && psvae_aligned16(table) && psvae_aligned16(out), PSVAE_EINVAL,
+                  "%s: null or misaligned pointer", fn);
+    hipLaunchKernelGGL(embedding_fwd_kernel, dim3(grid_for((long long)V * (D / 4), 256, 8192)), dim3(256), 0,
+                       (hipStream_t)stream, V, D / 4, n_rows, ids, (const float4 *)table, (float4 *)out);
+    PSVAE_CHECK_LAUNCH(fn);
+    return PSVAE_OK;
+}
+
+extern "C" int psvae_onehot_f32(int V, const int32_t *ids, float *out, int ld, void *stream) {
+    const char *fn = "psvae_onehot_f32";
+    PSVAE_REQUIRE(V >= 0 && ld > 0 && ld % 4 == 0, PSVAE_EINVAL, "%s: ld=%d must be a positive multiple of 4", fn, ld);
+    if (V == 0) return PSVAE_OK;
+    PSVAE_REQUIRE(ids && out && psvae_aligned16(out), PSVAE_EINVAL, "%s: null or misaligned pointer", fn);
+    hipLaunchKernelGGL(onehot_kernel, dim3(grid_for((long long)V * (ld / 4), 256, 16384)), dim3(256), 0,
+                       (hipStream_t)stream, V, ids, (float4 *)out, ld / 4);
+    PSVAE_CHECK_LAUNCH(fn);
     return PSVAE_OK;
 }
 

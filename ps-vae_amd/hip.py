@@ -28,6 +28,8 @@ _SIGNATURES = {
                                       _c_int, _p, _p]),
     'psvae_embed_atom_bwd': (_c_int, [_c_int, _p, _p, _p, _p] + [_c_int] * 6 + [_p, _p, _p, _p]),
     'psvae_embed_atom_onehot': (_c_int, [_c_int, _p, _p, _p, _c_int, _c_int, _c_int, _p, _c_int, _p]),
+    'psvae_embedding_fwd': (_c_int, [_c_int, _c_int, _c_int, _p, _p, _p, _p]),
+    'psvae_onehot_f32': (_c_int, [_c_int, _p, _p, _c_int, _p]),
     'psvae_gine_aggregate_fwd': (_c_int, [_c_int, _c_int, _c_int, _p, _c_int, _p, _p, _p, _p, _p, _c_int, _p]),
     'psvae_gine_aggregate_bwd_workspace_bytes': (_c_size, [_c_int, _c_int, _c_int]),
     'psvae_gine_aggregate_bwd': (_c_int, [_c_int, _c_int, _c_int, _p, _c_int, _p, _p, _c_int, _p, _p, _p, _p,
@@ -49,6 +51,8 @@ _SIGNATURES = {
     'psvae_rsample_kl_bwd': (_c_int, [_c_int, _c_int, _p, _p, _p, _p, _p, _p, _p, _p]),
     'psvae_gru_cell_fwd': (_c_int, [_c_int, _c_int, _p, _p, _p, _p, _p, _p]),
     'psvae_gru_cell_bwd': (_c_int, [_c_int, _c_int, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    'psvae_gru_seq_fwd': (_c_int, [_c_int, _c_int, _c_int, _p, _p, _p, _p, _p, _p, _p, _p]),
+    'psvae_gru_seq_bwd': (_c_int, [_c_int, _c_int, _c_int, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     'psvae_pair_gather_fwd': (_c_int, [_c_int, _c_int, _c_int, _p, _c_int, _p, _c_int, _p, _p, _p, _p, _p]),
     'psvae_pair_gather_bwd': (_c_int, [_c_int, _c_int, _c_int, _p, _p, _p, _p, _p, _p, _p, _c_int, _p, _c_int, _p]),
     'psvae_link_ce_workspace_bytes': (_c_size, [_c_int]),
@@ -344,6 +348,17 @@ def embed_atom_bwd(x, xp, xq, g, ga, gp, gq):
                                       ptr(gq, torch.float32), _stream()), 'psvae_embed_atom_bwd')
 
 
+def embedding_fwd(ids, table, out):
+    _check(lib().psvae_embedding_fwd(ids.numel(), table.shape[1], table.shape[0], ptr(ids, torch.int32),
+                                     ptr(table, torch.float32), ptr(out, torch.float32), _stream()),
+           'psvae_embedding_fwd')
+
+
+def onehot(ids, out):
+    _check(lib().psvae_onehot_f32(ids.numel(), ptr(ids, torch.int32), ptr(out, torch.float32), out.stride(0), _stream()),
+           'psvae_onehot_f32')
+
+
 def embed_trans_fwd(x, xp, xq, sizes, T, out):
     na, npc, nq = sizes
     po, ldo = _rows(out)
@@ -397,6 +412,24 @@ def gru_cell_bwd(gates, gh, h_prev, dh, dh_extra, dgi, dgh, dh_prev):
     f = torch.float32
     _check(lib().psvae_gru_cell_bwd(B, H, ptr(gates, f), ptr(gh, f), ptr(h_prev, f), ptr(dh, f), ptr(dh_extra, f),
                                     ptr(dgi, f), ptr(dgh, f), ptr(dh_prev, f), _stream()), 'psvae_gru_cell_bwd')
+
+
+GRU_SEQ_MAX_H = 256
+
+
+def gru_seq_fwd(gi, h0, w_hh, b_hh, hall, gates, ghn):
+    T, B, H3 = gi.shape
+    f = torch.float32
+    _check(lib().psvae_gru_seq_fwd(T, B, H3 // 3, ptr(gi, f), ptr(h0, f), ptr(w_hh, f), ptr(b_hh, f), ptr(hall, f),
+                                   ptr(gates, f), ptr(ghn, f), _stream()), 'psvae_gru_seq_fwd')
+
+
+def gru_seq_bwd(gates, ghn, hall, g_out, w_hh_t, dgi, dgh, dh0):
+    T, B, H3 = gates.shape
+    f = torch.float32
+    _check(lib().psvae_gru_seq_bwd(T, B, H3 // 3, ptr(gates, f), ptr(ghn, f), ptr(hall, f), ptr(g_out, f),
+                                   ptr(w_hh_t, f), ptr(dgi, f), ptr(dgh, f), ptr(dh0, f), _stream()),
+           'psvae_gru_seq_bwd')
 
 
 def pair_gather_fwd(h, z, src, dst, graph, feats):

@@ -75,7 +75,9 @@ class VAEPieceDecoder(nn.Module):
         init_hidden = run_linear(self.latent_to_rnn_hidden, z_vecs)
         if rnn.num_layers == 1 and not rnn.bidirectional and rnn.bias:
             # time-major ids -> [T,B,E] embeddings -> HIP GRU; logits returned batch-major
-            emb = self.piece_embedding(pieces[:, :-1].t())
+            ids = pieces[:, :-1].t().contiguous().to(torch.int32)
+            table = self.piece_embedding.weight
+            emb = ops.embedding(ids, table) if table.shape[1] % 4 == 0 else self.piece_embedding(ids.long())
             hs = ops.gru(emb, init_hidden, rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.bias_ih_l0, rnn.bias_hh_l0)
             return run_linear(self.to_vocab, hs).transpose(0, 1)
         output, _ = rnn(self.piece_embedding(pieces)[:, :-1], init_hidden.unsqueeze(0))

@@ -315,6 +315,42 @@ def embed_atom(x, xp, xq, e_atom, e_piece, e_pos):
     return _EmbedAtom.apply(x, xp, xq, e_atom, e_piece, e_pos)
 
 
+# ------------------------------------------------------------------------ one embedding table
+class _Embedding(Function):
+    """table[ids] with a deterministic backward: the table gradient is indicator^T g on the GEMM
+    (fixed summation order), not atomic adds or a sort."""
+
+    @staticmethod
+    def forward(ctx, ids, table):
+        table = table.contiguous()
+        flat = ids.reshape(-1)
+        out = torch.empty(flat.numel(), table.shape[1], dtype=torch.float32, device=table.device)
+        hip.embedding_fwd(flat, table, out)
+        ctx.save_for_backward(flat)
+        ctx.rows = table.shape[0]
+        return out.view(*ids.shape, table.shape[1])
+
+    @staticmethod
+    def backward(ctx, g):
+        flat, = ctx.saved_tensors
+        V, D = flat.numel(), g.shape[-1]
+        g2 = g.reshape(V, D)
+        g2 = g2 if (g2.dtype == torch.float32 and g2.is_contiguous()) else g2.float().contiguous()
+        r4 = (ctx.rows + 3) // 4 * 4
+        if V == 0:
+            return None, torch.zeros(ctx.rows, D, dtype=torch.float32, device=g2.device)
+        ind = torch.empty(V, r4, dtype=torch.float32, device=g2.device)
+        hip.onehot(flat, ind)
+        full = torch.empty(r4, D, dtype=torch.float32, device=g2.device)
+        hip.gemm(r4, D, V, ind, 1, r4, g2, D, 1, full, D, split_k=0)
+        return None, full[:ctx.rows]
+
+
+def embedding(ids, table):
+    """table[ids] for int32 ids of any shape -> [..., D] (D % 4 == 0)."""
+    return _Embedding.apply(ids, table)
+
+
 # ------------------------------------------------------------------------ first encoder layer on ids
 class EmbeddedIds:
     """The atoms of a batch as embedding ids plus the three tables, standing for the rows
@@ -458,15 +494,21 @@ class _Gru(Function):
         x = x.contiguous()
         w_ih, w_hh = w_ih.contiguous(), w_hh.contiguous()
         gi = torch.empty(T, B, 3 * H, **f32)
-        gh = torch.empty(T, B, 3 * H, **f32)
         gates = torch.empty(T, B, 3 * H, **f32)
         hall = torch.empty(T + 1, B, H, **f32)
-        hall[0].copy_(h0)
         if T * B:
             hip.gemm(T * B, 3 * H, E, x.view(T * B, E), E, 1, w_ih, 1, E, gi.view(T * B, 3 * H), 3 * H, bias=b_ih)
-        for t in range(T):
-            hip.gemm(B, 3 * H, H, hall[t], H, 1, w_hh, 1, H, gh[t], 3 * H, bias=b_hh)
-            hip.gru_cell_fwd(gi[t], gh[t], hall[t], hall[t + 1], gates[t])
+        ctx.seq = H % 4 == 0 and H <= hip.GRU_SEQ_MAX_H
+        if ctx.seq:
+            # the whole recurrence in one launch: a workgroup per 16 molecules walks all T steps
+            gh = torch.empty(T, B, H, **f32)       # only the n-gate part is needed afterwards
+            hip.gru_seq_fwd(gi, h0.contiguous(), w_hh, b_hh, hall, gates, gh)
+        else:
+            gh = torch.empty(T, B, 3 * H, **f32)
+            hall[0].copy_(h0)
+            for t in range(T):
+                hip.gemm(B, 3 * H, H, hall[t], H, 1, w_hh, 1, H, gh[t], 3 * H, bias=b_hh)
+                hip.gru_cell_fwd(gi[t], gh[t], hall[t], hall[t + 1], gates[t])
         ctx.save_for_backward(x, w_ih, w_hh, gh, gates, hall)
         ctx.has_bias = (b_ih is not None, b_hh is not None)
         return hall[1:]
@@ -480,12 +522,16 @@ class _Gru(Function):
         g_out = g_out if (g_out.dtype == torch.float32 and g_out.is_contiguous()) else g_out.float().contiguous()
         dgi = torch.empty(T, B, 3 * H, **f32)
         dgh = torch.empty(T, B, 3 * H, **f32)
-        dh = torch.zeros(B, H, **f32)          # gradient flowing into h_t from step t+1
-        nxt = torch.empty(B, H, **f32)
-        for t in range(T - 1, -1, -1):
-            hip.gru_cell_bwd(gates[t], gh[t], hall[t], g_out[t], dh, dgi[t], dgh[t], nxt)
-            hip.gemm(B, H, 3 * H, dgh[t], 3 * H, 1, w_hh, H, 1, nxt, H, accumulate=True)   # + dgh W_hh
-            dh, nxt = nxt, dh
+        if ctx.seq:
+            dh = torch.empty(B, H, **f32)
+            hip.gru_seq_bwd(gates, gh, hall, g_out, w_hh.t().contiguous(), dgi, dgh, dh)
+        else:
+            dh = torch.zeros(B, H, **f32)          # gradient flowing into h_t from step t+1
+            nxt = torch.empty(B, H, **f32)
+            for t in range(T - 1, -1, -1):
+                hip.gru_cell_bwd(gates[t], gh[t], hall[t], g_out[t], dh, dgi[t], dgh[t], nxt)
+                hip.gemm(B, H, 3 * H, dgh[t], 3 * H, 1, w_hh, H, 1, nxt, H, accumulate=True)   # + dgh W_hh
+                dh, nxt = nxt, dh
         g_wih, g_whh = torch.empty_like(w_ih), torch.empty_like(w_hh)
         g_bih = torch.empty(3 * H, **f32) if ctx.has_bias[0] else None
         g_bhh = torch.empty(3 * H, **f32) if ctx.has_bias[1] else None

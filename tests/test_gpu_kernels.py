@@ -333,11 +333,14 @@ def test_affine_merge(C, J, K, bias):
             close(got.grad, want.grad, what=f'grad {name}')
 
 
-@pytest.mark.parametrize('T,B', [(1, 3), (7, 300), (9, 33)])
-def test_gru_fwd_bwd(T, B):
+@pytest.mark.parametrize('T,B,E,H', [(1, 3, 100, 200), (7, 300, 100, 200), (9, 33, 100, 200), (5, 17, 12, 20),
+                                     (4, 64, 8, 4), (3, 40, 16, 256), (3, 9, 16, 260)])
+def test_gru_fwd_bwd(T, B, E, H):
+    """The GRU of the piece language model against float64 nn.GRU: the one-launch recurrence
+    (H a multiple of 4 up to 256: full and partial blocks of 16 hidden units, batch sizes that
+    are no multiple of 16) and the per-step kernels (H = 260)."""
     from ps_vae_amd import ops
     d = dev()
-    E, H = 100, 200
     torch.manual_seed(T * 100 + B)
     ref = torch.nn.GRU(E, H, batch_first=True).double()
     x = torch.randn(B, T, E, dtype=torch.float64, requires_grad=True)
@@ -357,6 +360,22 @@ def test_gru_fwd_bwd(T, B):
     for p, r, name in zip(params, (ref.weight_ih_l0, ref.weight_hh_l0, ref.bias_ih_l0, ref.bias_hh_l0),
                           ('w_ih', 'w_hh', 'b_ih', 'b_hh')):
         close(p.grad, r.grad, what=f'd GRU / d {name}')
+
+
+def test_embedding_fwd_bwd():
+    from ps_vae_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(4)
+    table = torch.randn(302, 100, generator=g, dtype=torch.float64, requires_grad=True)
+    ids = torch.randint(0, 302, (11, 700), generator=g)
+    gy = torch.randn(11, 700, 100, generator=g, dtype=torch.float64)
+    out = torch.nn.functional.embedding(ids, table)
+    out.backward(gy)
+    td = table.detach().float().to(d).requires_grad_()
+    outd = ops.embedding(ids.to(torch.int32).to(d), td)
+    outd.backward(gy.float().to(d))
+    assert torch.equal(outd.cpu(), out.detach().float())
+    close(td.grad, table.grad, what='embedding table gradient')
 
 
 def make_pairs(B, N, seed, p=0.15):
