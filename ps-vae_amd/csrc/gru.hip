@@ -8,12 +8,15 @@
 //     r = s(gi_r + gh_r), z = s(gi_z + gh_z), n = tanh(gi_n + r gh_n), h' = (1 - z) n + z h
 // (PyTorch gate order r, z, n; gi = x W_ih^T + b_ih comes from one large product beforehand).
 // Hidden units are cut into blocks of 16; wave w owns blocks w, w + 4, ... and, for each, the
-// three gate tiles of those units, so the gate arithmetic runs on the accumulators where they
-// are (D layout: lane = unit, registers = 4 batch rows) and the new hidden state goes straight
-// back to LDS as the next step's A operand.  h lives in LDS k-major ([unit][row], row stride 20
-// floats: the four k groups of a wave read disjoint banks); W_hh (3H x H, L2-resident) is read
-// 16 bytes per lane along k.  Within a 16-deep k block lane group q takes k = 16b + 4q + e in
-// MFMA number e - for A and B alike - so the sum over k is complete whatever the order.
+// three gate tiles of those units.  The product is taken transposed (gh^T = W_hh h^T: A = W_hh,
+// B = h^T), so that in the accumulator layout a lane is a batch row and its four registers are
+// four CONSECUTIVE hidden units: the gate arithmetic runs on the accumulators where they are and
+// every global access of the step (gi, gates, hidden states) is 16 bytes per lane.  The new
+// hidden state goes straight back to LDS as the next step's B operand.  h lives in LDS k-major
+// ([unit][row], row stride 20 floats: the four k groups of a wave read disjoint banks); W_hh
+// (3H x H, L2-resident) is read 16 bytes per lane along k, two k blocks ahead.  Within a 16-deep
+// k block lane group q takes k = 16b + 4q + e in MFMA number e - for A and B alike - so the sum
+// over k is complete whatever the order.
 //
 // Backward mirrors it: dgh (16 x 3H, k-major in LDS) times W_hh gives the gradient that flows to
 // the previous step, the gate derivatives are evaluated in the same register layout, and the
@@ -65,38 +68,36 @@ __global__ __launch_bounds__(GRU_THREADS, 1) void gru_seq_fwd_kernel(GruFwdArgs 
     }
     __syncthreads();
 
+    // A operand rows: gate c, unit 16 blk + jl -> row c*H + unit of W_hh (clamped for the padded
+    // units, whose results are never stored); 16 bytes along k per lane
+    const float *wrow[JB][3];
+#pragma unroll
+    for (int q = 0; q < JB; ++q) {
+        const int u = min((wave + 4 * q) * 16 + jl, H - 1);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) wrow[q][c] = a.w_hh + (long long)(c * H + u) * H;
+    }
+    const int brow = row0 + jl;                 // the batch row of this lane in the accumulator layout
+    const bool row_ok = brow < B;
     for (int t = 0; t < a.T; ++t) {
         const float *hc = hk[t & 1];
         float *hn = hk[(t + 1) & 1];
-        const float *gi_t = a.gi + (long long)t * B * H3;
-        // input projections of this step, requested before the products they do not depend on
-        float gi_r[JB][4], gi_z[JB][4], gi_n[JB][4];
+        // input projections of this step (units 16 blk + 4g .. +3 of row brow: 16 bytes per gate),
+        // requested before the products they do not depend on
+        float4 gi4[JB][3];
 #pragma unroll
         for (int q = 0; q < JB; ++q) {
-            const int j = (wave + 4 * q) * 16 + jl;
+            const int u0 = (wave + 4 * q) * 16 + 4 * g;
+            const bool ok = (wave + 4 * q) < nblk && u0 < H && row_ok;
+            const float *p = a.gi + (ok ? ((long long)t * B + brow) * H3 + u0 : 0);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = row0 + 4 * g + r;
-                const bool ok = (wave + 4 * q) < nblk && j < H && row < B;
-                const long long o = ok ? (long long)row * H3 + j : 0;
-                gi_r[q][r] = gi_t[o], gi_z[q][r] = gi_t[o + (ok ? H : 0)], gi_n[q][r] = gi_t[o + (ok ? 2 * H : 0)];
-            }
+            for (int c = 0; c < 3; ++c) gi4[q][c] = *reinterpret_cast<const float4 *>(p + (ok ? c * H : 0));
         }
         f32x4 acc[JB][3];
 #pragma unroll
         for (int q = 0; q < JB; ++q)
 #pragma unroll
             for (int c = 0; c < 3; ++c) acc[q][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        // B operand rows: gate c, unit j -> row c*H + j of W_hh (clamped for the padded units, whose
-        // columns are never stored); 16 bytes along k per lane
-        const float *wrow[JB][3];
-#pragma unroll
-        for (int q = 0; q < JB; ++q) {
-            const int j = min((wave + 4 * q) * 16 + jl, H - 1);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) wrow[q][c] = a.w_hh + (long long)(c * H + j) * H;
-        }
-        float4 wcur[JB][3], wnxt[JB][3];
         auto load_w = [&](float4 (&w)[JB][3], int kb) {
             const int k = min(16 * kb + 4 * g, H - 4);   // the padded k tail multiplies zero rows of h
 #pragma unroll
@@ -106,56 +107,81 @@ __global__ __launch_bounds__(GRU_THREADS, 1) void gru_seq_fwd_kernel(GruFwdArgs 
                     for (int c = 0; c < 3; ++c) w[q][c] = *reinterpret_cast<const float4 *>(wrow[q][c] + k);
                 }
         };
-        load_w(wcur, 0);
-        for (int kb = 0; kb < nblk; ++kb) {
-            if (kb + 1 < nblk) load_w(wnxt, kb + 1);
-            float av[4];
+        auto multiply = [&](const float4 (&w)[JB][3], int kb) {
+            float hv[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) av[e] = hc[(16 * kb + 4 * g + e) * GRU_LD + jl];
+            for (int e = 0; e < 4; ++e) hv[e] = hc[(16 * kb + 4 * g + e) * GRU_LD + jl];
+            // e outermost: consecutive MFMAs hit different accumulators (a dependent pair costs 40
+            // cycles, an independent one 32)
 #pragma unroll
-            for (int q = 0; q < JB; ++q)
-                if (wave + 4 * q < nblk) {
+            for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const float4 w = wcur[q][c];
-                        acc[q][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], w.x, acc[q][c], 0, 0, 0);
-                        acc[q][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], w.y, acc[q][c], 0, 0, 0);
-                        acc[q][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], w.z, acc[q][c], 0, 0, 0);
-                        acc[q][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], w.w, acc[q][c], 0, 0, 0);
+                for (int q = 0; q < JB; ++q)
+                    if (wave + 4 * q < nblk) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const float wv = e == 0 ? w[q][c].x : (e == 1 ? w[q][c].y : (e == 2 ? w[q][c].z : w[q][c].w));
+                            acc[q][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, hv[e], acc[q][c], 0, 0, 0);
+                        }
                     }
-                }
-#pragma unroll
-            for (int q = 0; q < JB; ++q)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) wcur[q][c] = wnxt[q][c];
+        };
+        // W_hh fragments travel two k blocks ahead of their use (one wave per SIMD: nothing else
+        // hides the L2 latency)
+        float4 w0[JB][3], w1[JB][3], w2[JB][3];
+        load_w(w0, 0);
+        if (nblk > 1) load_w(w1, 1);
+        for (int kb = 0; kb < nblk; kb += 3) {
+            if (kb + 2 < nblk) load_w(w2, kb + 2);
+            multiply(w0, kb);
+            if (kb + 1 < nblk) {
+                if (kb + 3 < nblk) load_w(w0, kb + 3);
+                multiply(w1, kb + 1);
+            }
+            if (kb + 2 < nblk) {
+                if (kb + 4 < nblk) load_w(w1, kb + 4);
+                multiply(w2, kb + 2);
+            }
         }
-        // gates on the accumulators: lane = unit j, registers = rows 4g .. 4g+3
+        // gates on the accumulators: lane = batch row, registers = units u0 .. u0+3
 #pragma unroll
         for (int q = 0; q < JB; ++q) {
             const int blk = wave + 4 * q;
-            const int j = blk * 16 + jl;
-            if (blk >= nblk || j >= H) continue;
-            const float br = a.b_hh ? a.b_hh[j] : 0.f, bz = a.b_hh ? a.b_hh[H + j] : 0.f;
-            const float bn = a.b_hh ? a.b_hh[2 * H + j] : 0.f;
-            const float4 hp4 = *reinterpret_cast<const float4 *>(hc + j * GRU_LD + 4 * g);
-            const float hp[4] = {hp4.x, hp4.y, hp4.z, hp4.w};
-            float hnew[4];
+            const int u0 = blk * 16 + 4 * g;
+            if (blk >= nblk || u0 >= H) continue;
+            float4 b3[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                b3[c] = a.b_hh ? *reinterpret_cast<const float4 *>(a.b_hh + c * H + u0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float bias[3][4] = {{b3[0].x, b3[0].y, b3[0].z, b3[0].w}, {b3[1].x, b3[1].y, b3[1].z, b3[1].w},
+                                      {b3[2].x, b3[2].y, b3[2].z, b3[2].w}};
+            const float gir[4] = {gi4[q][0].x, gi4[q][0].y, gi4[q][0].z, gi4[q][0].w};
+            const float giz[4] = {gi4[q][1].x, gi4[q][1].y, gi4[q][1].z, gi4[q][1].w};
+            const float gin[4] = {gi4[q][2].x, gi4[q][2].y, gi4[q][2].z, gi4[q][2].w};
+            float rr[4], zz[4], nn[4], gn[4], hnew[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = row0 + 4 * g + r;
-                const float ghr = acc[q][0][r] + br, ghz = acc[q][1][r] + bz, ghn = acc[q][2][r] + bn;
-                const float rr = sigmoidf_(gi_r[q][r] + ghr);
-                const float zz = sigmoidf_(gi_z[q][r] + ghz);
-                const float nn = tanhf(gi_n[q][r] + rr * ghn);
-                hnew[r] = (1.0f - zz) * nn + zz * hp[r];
-                if (row < B) {
-                    const long long o = ((long long)t * B + row) * H3 + j;
-                    if (a.gates) a.gates[o] = rr, a.gates[o + H] = zz, a.gates[o + 2 * H] = nn;
-                    if (a.ghn) a.ghn[((long long)t * B + row) * H + j] = ghn;
-                    a.hall[((long long)(t + 1) * B + row) * H + j] = hnew[r];
-                }
+                const float ghr = acc[q][0][r] + bias[0][r], ghz = acc[q][1][r] + bias[1][r];
+                gn[r] = acc[q][2][r] + bias[2][r];
+                rr[r] = sigmoidf_(gir[r] + ghr);
+                zz[r] = sigmoidf_(giz[r] + ghz);
+                nn[r] = tanhf(gin[r] + rr[r] * gn[r]);
+                const float hp = hc[(u0 + r) * GRU_LD + jl];
+                hnew[r] = (1.0f - zz[r]) * nn[r] + zz[r] * hp;
+                hn[(u0 + r) * GRU_LD + jl] = row_ok ? hnew[r] : 0.f;
             }
-            *reinterpret_cast<float4 *>(hn + j * GRU_LD + 4 * g) = make_float4(hnew[0], hnew[1], hnew[2], hnew[3]);
+            if (row_ok) {
+                const long long o = ((long long)t * B + brow) * H3 + u0;
+                if (a.gates) {
+                    *reinterpret_cast<float4 *>(a.gates + o) = make_float4(rr[0], rr[1], rr[2], rr[3]);
+                    *reinterpret_cast<float4 *>(a.gates + o + H) = make_float4(zz[0], zz[1], zz[2], zz[3]);
+                    *reinterpret_cast<float4 *>(a.gates + o + 2 * H) = make_float4(nn[0], nn[1], nn[2], nn[3]);
+                }
+                if (a.ghn)
+                    *reinterpret_cast<float4 *>(a.ghn + ((long long)t * B + brow) * H + u0) =
+                        make_float4(gn[0], gn[1], gn[2], gn[3]);
+                *reinterpret_cast<float4 *>(a.hall + ((long long)(t + 1) * B + brow) * H + u0) =
+                    make_float4(hnew[0], hnew[1], hnew[2], hnew[3]);
+            }
         }
         __syncthreads();
     }
@@ -193,24 +219,30 @@ __global__ __launch_bounds__(GRU_THREADS, 1) void gru_seq_bwd_kernel(GruBwdArgs 
     for (int q = 0; q < JB; ++q)
 #pragma unroll
         for (int r = 0; r < 4; ++r) dh[q][r] = 0.f;
+    const int brow = row0 + jl;                 // the batch row of this lane in the accumulator layout
+    const bool row_ok = brow < B;
+    const float *wrow[JB];                      // A operand rows: unit 16 blk + jl of W_hh^T (clamped)
+#pragma unroll
+    for (int q = 0; q < JB; ++q) wrow[q] = a.w_hh_t + (long long)min((wave + 4 * q) * 16 + jl, H - 1) * H3;
 
-    // saved values of one step in the register layout of the gate arithmetic
+    // saved values of one step in the register layout of the gate arithmetic: for row brow, units
+    // u0 .. u0+3 of every block this wave owns (16 bytes per array)
     struct Saved {
-        float rr[JB][4], zz[JB][4], nn[JB][4], gn[JB][4], hp[JB][4], go[JB][4];
+        float4 rr[JB], zz[JB], nn[JB], gn[JB], hp[JB], go[JB];
     };
     auto fetch = [&](Saved &s, int t) {
 #pragma unroll
         for (int q = 0; q < JB; ++q) {
-            const int j = (wave + 4 * q) * 16 + jl;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = row0 + 4 * g + r;
-                const bool ok = (wave + 4 * q) < nblk && j < H && row < B;
-                const long long o3 = ok ? ((long long)t * B + row) * H3 + j : 0;
-                const long long o1 = ok ? ((long long)t * B + row) * H + j : 0;
-                s.rr[q][r] = a.gates[o3], s.zz[q][r] = a.gates[o3 + (ok ? H : 0)], s.nn[q][r] = a.gates[o3 + (ok ? 2 * H : 0)];
-                s.gn[q][r] = a.ghn[o1], s.hp[q][r] = a.hall[o1], s.go[q][r] = a.g_out[o1];
-            }
+            const int u0 = (wave + 4 * q) * 16 + 4 * g;
+            const bool ok = (wave + 4 * q) < nblk && u0 < H && row_ok;
+            const long long o3 = ok ? ((long long)t * B + brow) * H3 + u0 : 0;
+            const long long o1 = ok ? ((long long)t * B + brow) * H + u0 : 0;
+            s.rr[q] = *reinterpret_cast<const float4 *>(a.gates + o3);
+            s.zz[q] = *reinterpret_cast<const float4 *>(a.gates + o3 + (ok ? H : 0));
+            s.nn[q] = *reinterpret_cast<const float4 *>(a.gates + o3 + (ok ? 2 * H : 0));
+            s.gn[q] = *reinterpret_cast<const float4 *>(a.ghn + o1);
+            s.hp[q] = *reinterpret_cast<const float4 *>(a.hall + o1);
+            s.go[q] = *reinterpret_cast<const float4 *>(a.g_out + o1);
         }
     };
     Saved cur;
@@ -227,65 +259,81 @@ __global__ __launch_bounds__(GRU_THREADS, 1) void gru_seq_bwd_kernel(GruBwdArgs 
 #pragma unroll
         for (int q = 0; q < JB; ++q) {
             const int blk = wave + 4 * q;
-            const int j = blk * 16 + jl;
-            if (blk >= nblk || j >= H) continue;
-            float vr[4], vz[4], vn[4];
+            const int u0 = blk * 16 + 4 * g;
+            if (blk >= nblk || u0 >= H) continue;
+            const float rr[4] = {cur.rr[q].x, cur.rr[q].y, cur.rr[q].z, cur.rr[q].w};
+            const float zz[4] = {cur.zz[q].x, cur.zz[q].y, cur.zz[q].z, cur.zz[q].w};
+            const float nn[4] = {cur.nn[q].x, cur.nn[q].y, cur.nn[q].z, cur.nn[q].w};
+            const float gn[4] = {cur.gn[q].x, cur.gn[q].y, cur.gn[q].z, cur.gn[q].w};
+            const float hp[4] = {cur.hp[q].x, cur.hp[q].y, cur.hp[q].z, cur.hp[q].w};
+            const float go[4] = {cur.go[q].x, cur.go[q].y, cur.go[q].z, cur.go[q].w};
+            float vr[4], vz[4], vn[4], vnr[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = row0 + 4 * g + r;
-                const float rr = cur.rr[q][r], zz = cur.zz[q][r], nn = cur.nn[q][r];
-                const float d = cur.go[q][r] + dh[q][r];
-                const float dn_pre = d * (1.0f - zz) * (1.0f - nn * nn);
-                const float dz_pre = d * (cur.hp[q][r] - nn) * zz * (1.0f - zz);
-                const float dr_pre = dn_pre * cur.gn[q][r] * rr * (1.0f - rr);
-                dzh[q][r] = d * zz;
-                vr[r] = dr_pre, vz[r] = dz_pre, vn[r] = dn_pre * rr;
-                if (row < B) {
-                    const long long o = ((long long)t * B + row) * H3 + j;
-                    a.dgi[o] = dr_pre, a.dgi[o + H] = dz_pre, a.dgi[o + 2 * H] = dn_pre;
-                    a.dgh[o] = dr_pre, a.dgh[o + H] = dz_pre, a.dgh[o + 2 * H] = vn[r];
-                } else {
-                    vr[r] = vz[r] = vn[r] = 0.f;
-                }
+                const float d = go[r] + dh[q][r];
+                const float dn_pre = d * (1.0f - zz[r]) * (1.0f - nn[r] * nn[r]);
+                const float dz_pre = d * (hp[r] - nn[r]) * zz[r] * (1.0f - zz[r]);
+                const float dr_pre = dn_pre * gn[r] * rr[r] * (1.0f - rr[r]);
+                dzh[q][r] = d * zz[r];
+                vr[r] = row_ok ? dr_pre : 0.f, vz[r] = row_ok ? dz_pre : 0.f;
+                vn[r] = row_ok ? dn_pre : 0.f, vnr[r] = row_ok ? dn_pre * rr[r] : 0.f;
+                dc[(u0 + r) * GRU_LD + jl] = vr[r];
+                dc[(H + u0 + r) * GRU_LD + jl] = vz[r];
+                dc[(2 * H + u0 + r) * GRU_LD + jl] = vnr[r];
             }
-            *reinterpret_cast<float4 *>(dc + j * GRU_LD + 4 * g) = make_float4(vr[0], vr[1], vr[2], vr[3]);
-            *reinterpret_cast<float4 *>(dc + (H + j) * GRU_LD + 4 * g) = make_float4(vz[0], vz[1], vz[2], vz[3]);
-            *reinterpret_cast<float4 *>(dc + (2 * H + j) * GRU_LD + 4 * g) = make_float4(vn[0], vn[1], vn[2], vn[3]);
+            if (row_ok) {
+                const long long o = ((long long)t * B + brow) * H3 + u0;
+                const float4 r4 = make_float4(vr[0], vr[1], vr[2], vr[3]), z4 = make_float4(vz[0], vz[1], vz[2], vz[3]);
+                *reinterpret_cast<float4 *>(a.dgi + o) = r4;
+                *reinterpret_cast<float4 *>(a.dgi + o + H) = z4;
+                *reinterpret_cast<float4 *>(a.dgi + o + 2 * H) = make_float4(vn[0], vn[1], vn[2], vn[3]);
+                *reinterpret_cast<float4 *>(a.dgh + o) = r4;
+                *reinterpret_cast<float4 *>(a.dgh + o + H) = z4;
+                *reinterpret_cast<float4 *>(a.dgh + o + 2 * H) = make_float4(vnr[0], vnr[1], vnr[2], vnr[3]);
+            }
         }
         __syncthreads();
         if (t > 0) fetch(cur, t - 1);   // the next step's saved values travel while the product runs
 
         f32x4 acc[JB];
-        const float *wrow[JB];
 #pragma unroll
-        for (int q = 0; q < JB; ++q) {
-            acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            wrow[q] = a.w_hh_t + (long long)min((wave + 4 * q) * 16 + jl, H - 1) * H3;
-        }
-        float4 wcur[JB], wnxt[JB];
-        auto load_w = [&](float4 (&w)[JB], int kb) {
-            const int k = min(16 * kb + 4 * g, H3 - 4);
+        for (int q = 0; q < JB; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        constexpr int G = 4;            // k blocks per group; one group of W_hh^T fragments travels ahead
+        auto load_w = [&](float4 (&w)[G][JB], int kb0) {
 #pragma unroll
-            for (int q = 0; q < JB; ++q)
-                if (wave + 4 * q < nblk) w[q] = *reinterpret_cast<const float4 *>(wrow[q] + k);
+            for (int u = 0; u < G; ++u) {
+                const int k = min(16 * (kb0 + u) + 4 * g, H3 - 4);   // the padded k tail multiplies zero rows
+#pragma unroll
+                for (int q = 0; q < JB; ++q)
+                    if (wave + 4 * q < nblk) w[u][q] = *reinterpret_cast<const float4 *>(wrow[q] + k);
+            }
         };
-        load_w(wcur, 0);
-        for (int kb = 0; kb < nkb; ++kb) {
-            if (kb + 1 < nkb) load_w(wnxt, kb + 1);
-            float av[4];
+        auto multiply = [&](const float4 (&w)[G][JB], int kb0) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) av[e] = dc[(16 * kb + 4 * g + e) * GRU_LD + jl];
+            for (int u = 0; u < G; ++u) {
+                if (kb0 + u >= nkb) break;
+                float dv[4];
 #pragma unroll
-            for (int q = 0; q < JB; ++q)
-                if (wave + 4 * q < nblk) {
-                    const float4 w = wcur[q];
-                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], w.x, acc[q], 0, 0, 0);
-                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], w.y, acc[q], 0, 0, 0);
-                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], w.z, acc[q], 0, 0, 0);
-                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], w.w, acc[q], 0, 0, 0);
-                }
+                for (int e = 0; e < 4; ++e) dv[e] = dc[(16 * (kb0 + u) + 4 * g + e) * GRU_LD + jl];
 #pragma unroll
-            for (int q = 0; q < JB; ++q) wcur[q] = wnxt[q];
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int q = 0; q < JB; ++q)
+                        if (wave + 4 * q < nblk) {
+                            const float wv = e == 0 ? w[u][q].x : (e == 1 ? w[u][q].y : (e == 2 ? w[u][q].z : w[u][q].w));
+                            acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, dv[e], acc[q], 0, 0, 0);
+                        }
+            }
+        };
+        float4 wa[G][JB], wb[G][JB];
+        load_w(wa, 0);
+        for (int kb = 0; kb < nkb; kb += 2 * G) {
+            if (kb + G < nkb) load_w(wb, kb + G);
+            multiply(wa, kb);
+            if (kb + G < nkb) {
+                if (kb + 2 * G < nkb) load_w(wa, kb + 2 * G);
+                multiply(wb, kb + G);
+            }
         }
 #pragma unroll
         for (int q = 0; q < JB; ++q)
@@ -294,13 +342,9 @@ __global__ __launch_bounds__(GRU_THREADS, 1) void gru_seq_bwd_kernel(GruBwdArgs 
     }
 #pragma unroll
     for (int q = 0; q < JB; ++q) {
-        const int j = (wave + 4 * q) * 16 + jl;
-        if (wave + 4 * q >= nblk || j >= H) continue;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = row0 + 4 * g + r;
-            if (row < B) a.dh0[(long long)row * H + j] = dh[q][r];
-        }
+        const int u0 = (wave + 4 * q) * 16 + 4 * g;
+        if (wave + 4 * q >= nblk || u0 >= H || !row_ok) continue;
+        *reinterpret_cast<float4 *>(a.dh0 + (long long)brow * H + u0) = make_float4(dh[q][0], dh[q][1], dh[q][2], dh[q][3]);
     }
 }
 
@@ -321,7 +365,9 @@ extern "C" int psvae_gru_seq_fwd(int T, int B, int H, const float *gi, const flo
     if (rc) return rc;
     if (B == 0) return PSVAE_OK;
     PSVAE_REQUIRE(h0 && w_hh && hall && (T == 0 || gi), PSVAE_EINVAL, "%s: null pointer", fn);
-    PSVAE_REQUIRE(psvae_aligned16(w_hh), PSVAE_EINVAL, "%s: w_hh must be 16-byte aligned", fn);
+    PSVAE_REQUIRE(psvae_aligned16(w_hh) && psvae_aligned16(gi) && psvae_aligned16(hall) && psvae_aligned16(gates) &&
+                      psvae_aligned16(ghn) && psvae_aligned16(b_hh),
+                  PSVAE_EINVAL, "%s: every array must be 16-byte aligned", fn);
     GruFwdArgs a{T, B, H, gi, h0, w_hh, b_hh, hall, gates, ghn};
     const int KP = (H + 15) & ~15, nblk = KP / 16, jb = psvae_cdiv(nblk, 4);
     const size_t lds = 2 * (size_t)KP * GRU_LD * sizeof(float);
@@ -346,7 +392,9 @@ extern "C" int psvae_gru_seq_bwd(int T, int B, int H, const float *gates, const 
     if (B == 0) return PSVAE_OK;
     PSVAE_REQUIRE(hall && w_hh_t && dh0 && (T == 0 || (gates && ghn && g_out && dgi && dgh)), PSVAE_EINVAL,
                   "%s: null pointer", fn);
-    PSVAE_REQUIRE(psvae_aligned16(w_hh_t), PSVAE_EINVAL, "%s: w_hh_t must be 16-byte aligned", fn);
+    PSVAE_REQUIRE(psvae_aligned16(w_hh_t) && psvae_aligned16(gates) && psvae_aligned16(ghn) && psvae_aligned16(hall) &&
+                      psvae_aligned16(g_out) && psvae_aligned16(dgi) && psvae_aligned16(dgh) && psvae_aligned16(dh0),
+                  PSVAE_EINVAL, "%s: every array must be 16-byte aligned", fn);
     GruBwdArgs a{T, B, H, gates, ghn, hall, g_out, w_hh_t, dgi, dgh, dh0};
     const int nblk = (H + 15) / 16, jb = psvae_cdiv(nblk, 4);
     const int K3P = (3 * H + 15) & ~15;
