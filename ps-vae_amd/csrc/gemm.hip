@@ -61,6 +61,7 @@ struct GemmArgs {
     int c_vec;            // C (and ws) rows may be written 16 bytes at a time; 2: and byte offsets fit 32 bits
     int nt_m, nt_n, bn;   // tiles and column-tile width
     int wn;               // wave grid of the panel kernel: 1 = 4 x 1, 2 = 2 x 2
+    int tail_begin;       // rows tail_begin .. K-1 of the contraction are added by the reduce kernel (K: none)
 };
 
 __device__ __forceinline__ void epilogue_store(const GemmArgs &g, int row, int col, float v) {
@@ -518,8 +519,52 @@ __global__ __launch_bounds__(THREADS) void gemm_generic_kernel(GemmArgs g) {
     }
 }
 
-// Sum the split-K slabs in slab order and apply the epilogue.
-__global__ void gemm_splitk_reduce_kernel(GemmArgs g) {
+// Sum the split-K slabs and apply the epilogue.  A block of 256 threads takes 64 groups of four
+// consecutive columns; its four waves each sum a quarter of the slabs (16-byte loads, eight in
+// flight), and wave 0 adds the four partial sums in wave order: the result does not depend on the
+// grid.  Needs a 16-byte aligned workspace (ws_ld is a multiple of 4 by construction).
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g) {
+    __shared__ float4 part[3][64];
+    const int ld4 = g.ws_ld >> 2;
+    const long long quads = (long long)g.M * ld4;
+    const int q = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int per = (g.split_k + 3) >> 2, z0 = q * per, z1 = min(g.split_k, z0 + per);
+    const float4 *ws4 = reinterpret_cast<const float4 *>(g.ws);
+    for (long long base = (long long)blockIdx.x * 64; base < quads; base += (long long)gridDim.x * 64) {
+        const long long idx = base + l;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx < quads) {
+#pragma unroll 8
+            for (int z = z0; z < z1; ++z) {
+                const float4 t = ws4[(long long)z * quads + idx];
+                v.x += t.x, v.y += t.y, v.z += t.z, v.w += t.w;
+            }
+        }
+        if (q) part[q - 1][l] = v;
+        __syncthreads();
+        if (q == 0 && idx < quads) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const float4 t = part[p][l];
+                v.x += t.x, v.y += t.y, v.z += t.z, v.w += t.w;
+            }
+            const int row = (int)(idx / ld4), col = (int)(idx % ld4) * 4;
+            const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (col + c >= g.n_ext) continue;
+                float r = e[c];
+                for (int k = g.tail_begin; k < g.K; ++k)   // ragged end of a tall-K product (fewer than 16 rows)
+                    r += g.A[row * g.sa_m + k * g.sa_k] * (col + c < g.N ? g.B[k * g.sb_k + (col + c) * g.sb_n] : 1.f);
+                epilogue_store(g, row, col + c, r);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// The same for a workspace that is not 16-byte aligned: one element per thread, slabs in order.
+__global__ void gemm_splitk_reduce_scalar_kernel(GemmArgs g) {
     const long long total = (long long)g.M * g.ws_ld;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
@@ -529,6 +574,173 @@ __global__ void gemm_splitk_reduce_kernel(GemmArgs g) {
         for (int z = 0; z < g.split_k; ++z) v += g.ws[(long long)z * total + idx];
         epilogue_store(g, row, col, v);
     }
+}
+
+void launch_splitk_reduce(const GemmArgs &g, hipStream_t s) {
+    const long long total = (long long)g.M * g.ws_ld;
+    if (psvae_aligned16(g.ws)) {
+        const long long nb = (total / 4 + 63) / 64;
+        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)(nb < 8192 ? nb : 8192)), dim3(256), 0, s, g);
+    } else {
+        const long long nb = (total + 255) / 256;
+        hipLaunchKernelGGL(gemm_splitk_reduce_scalar_kernel, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, s, g);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Tall-K weight gradients: C [M,N] (+ row sums) = A^T-like product with M, N <= 304 and K in the
+// hundred thousands (dW = dY^T X over all rows of the batch, both operands row-major with the
+// contracted index on the rows).  A workgroup of 8 waves owns a K chunk and one HALF of the output
+// columns (up to 304 x 160) and keeps it in registers: 4 x 2 waves, each 5 x 5 tiles of
+// v_mfma_f32_16x16x4_f32 = 100 accumulator registers per lane, two waves per SIMD.  The A operand is
+// therefore read twice (by the two halves of a chunk, placed on the same XCD so that the second read
+// is an L2 hit) and B once - the panel kernel reads B once per 64-row panel of the output, five times
+// for M = 300.  Operand rows go straight to LDS (16 bytes per lane, no staging registers) through a
+// ring of three stages; row strides of 304 and 176 floats (= 16 mod 32) put the four k groups of a
+// wave on disjoint banks.  The product is taken as (X^T dY)^T: a lane is an output row m and its four
+// registers four consecutive columns n, so the slab is written 16 bytes per lane.  Column N of the
+// B tile is preset to 1: the row sums (bias gradient) come out of the same MFMAs.  Slabs are summed
+// by gemm_splitk_reduce_kernel, which also adds the last K % 16 rows.
+// ------------------------------------------------------------------------------------------
+constexpr int TK_THREADS = 512, TK_BK = 16, TK_LDA = 304, TK_LDB = 176, TK_T = 5, TK_MAX = 304, TK_STAGES = 3;
+constexpr int TK_HALF = 160;   // output columns per workgroup
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct TallKArgs {
+    int M, N, K, n_ext;   // K: a multiple of TK_BK
+    const float *A;       // A(m,k) = A[k * lda + m]
+    long long lda;
+    const float *B;       // B(k,n) = B[k * ldb + n]
+    long long ldb;
+    float *ws;            // [chunks][M][ws_ld]
+    int ws_ld, k_chunk, halves, chunks;
+};
+
+__global__ __launch_bounds__(TK_THREADS, 2) void gemm_tallk_kernel(TallKArgs g) {
+    extern __shared__ __align__(16) float tk_lds[];   // 3 stages x (A tile [16][304] | B tile [16][176])
+    constexpr int TILE_A = TK_BK * TK_LDA, TILE_B = TK_BK * TK_LDB, STAGE = TILE_A + TILE_B;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int jl = lane & 15, kq = lane >> 4;
+    // blocks b and b + 8 (the two halves of one chunk) run on the same XCD
+    int z = blockIdx.x, half = 0;
+    if (g.halves == 2) half = (z >> 3) & 1, z = (z >> 4) * 8 + (z & 7);
+    if (z >= g.chunks) return;   // (the grid is padded to whole groups of 16 blocks)
+    const int k_begin = z * g.k_chunk, k_end = min(g.K, k_begin + g.k_chunk);
+    const int n_lo = half * TK_HALF;                                  // first output column of this half
+    const int n_cols = min(g.N, n_lo + TK_HALF) - n_lo;               // columns of B it loads (may be <= 0)
+    const int ntm = (g.M + 15) >> 4, ntn = (min(g.n_ext, n_lo + TK_HALF) - n_lo + 15) >> 4;
+    // Every wave multiplies a full 5 x 5 block of tiles, so the k loop has no branch: the last wave
+    // row / column slides back over its neighbour's tiles (19 tiles: 0-4, 5-9, 10-14, 14-18) and the
+    // duplicates are dropped at the store.
+    const int own_m = (wave & 3) * TK_T, own_n = (wave >> 2) * TK_T;
+    const int mt0 = max(0, min(own_m, ntm - TK_T)), nt0 = max(0, min(own_n, ntn - TK_T));
+
+    // columns the loads never write: zero, and 1 at column N of the B tile when row sums are asked for
+    for (int i = tid; i < TK_STAGES * STAGE; i += TK_THREADS) {
+        const int r = i % STAGE;
+        if (r < TILE_A) {
+            if (r % TK_LDA >= g.M) tk_lds[i] = 0.f;
+        } else {
+            const int col = (r - TILE_A) % TK_LDB;
+            if (col >= n_cols) tk_lds[i] = (n_lo + col == g.N && g.n_ext > g.N) ? 1.f : 0.f;
+        }
+    }
+    // One k-tile of both operands -> stage, each row in pieces of up to 1 KiB (64 lanes x 16 B) straight
+    // to LDS: a wave takes one piece index of rows r0, r0+4, r0+8, r0+12 of A and rows wave, wave+8 of B.
+    const int piece = wave & 1, r0 = wave >> 1, ca = piece * 256 + lane * 4, cb = lane * 4;
+    const bool a_on = ca < g.M, b_on = cb < n_cols;
+    auto issue = [&](int stage, int k0) {
+        float *dst = tk_lds + stage * STAGE;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {   // (row base: wave-uniform; lane part: ca)
+            const float *ra = g.A + (long long)(k0 + r0 + 4 * n) * g.lda;
+            if (a_on)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ra + ca),
+                                                 (__attribute__((address_space(3))) void *)(dst + (r0 + 4 * n) * TK_LDA + piece * 256),
+                                                 16, 0, 0);
+        }
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const float *rb = g.B + (long long)(k0 + wave + 8 * n) * g.ldb + n_lo;
+            if (b_on)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rb + cb),
+                                                 (__attribute__((address_space(3))) void *)(dst + TILE_A + (wave + 8 * n) * TK_LDB),
+                                                 16, 0, 0);
+        }
+    };
+    f32x4 acc[TK_T][TK_T];
+#pragma unroll
+    for (int i = 0; i < TK_T; ++i)
+#pragma unroll
+        for (int j = 0; j < TK_T; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // operand fragments of one k-step (4 k rows): 5 + 5 registers, two sets in flight
+    const int a_off = kq * TK_LDA + mt0 * 16 + jl, b_off = TILE_A + kq * TK_LDB + nt0 * 16 + jl;
+    auto fetch = [&](float (&av)[TK_T], float (&bv)[TK_T], const float *st, int ks) {
+#pragma unroll
+        for (int i = 0; i < TK_T; ++i) av[i] = st[a_off + ks * 4 * TK_LDA + 16 * i];
+#pragma unroll
+        for (int j = 0; j < TK_T; ++j) bv[j] = st[b_off + ks * 4 * TK_LDB + 16 * j];
+    };
+    auto multiply = [&](const float (&av)[TK_T], const float (&bv)[TK_T]) {
+#pragma unroll
+        for (int i = 0; i < TK_T; ++i)
+#pragma unroll
+            for (int j = 0; j < TK_T; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[j], av[i], acc[i][j], 0, 0, 0);
+    };
+
+    // Ring of three stages with ONE barrier per k-tile, placed in the middle of the tile: by then the
+    // tile after this one has landed (it was requested a whole tile earlier), so the last k-step of a
+    // tile can already fetch the first fragments of the next one, and the stage two tiles ahead -
+    // last read before every wave reached this barrier - is free to be refilled.
+    const int n_tiles = max(0, k_end - k_begin) / TK_BK;
+    if (n_tiles > 0) issue(0, k_begin);
+    if (n_tiles > 1) issue(1, k_begin + TK_BK);
+    __syncthreads();
+    float a0[TK_T], b0[TK_T], a1[TK_T], b1[TK_T];
+    fetch(a0, b0, tk_lds, 0);
+    int cur = 0;
+    for (int t = 0; t < n_tiles; ++t) {
+        const float *st = tk_lds + cur * STAGE;
+        const int nxt = cur == TK_STAGES - 1 ? 0 : cur + 1, nxt2 = nxt == TK_STAGES - 1 ? 0 : nxt + 1;
+        fetch(a1, b1, st, 1);
+        multiply(a0, b0);
+        fetch(a0, b0, st, 2);
+        multiply(a1, b1);
+        __syncthreads();
+        if (t + 2 < n_tiles) issue(nxt2, k_begin + (t + 2) * TK_BK);
+        fetch(a1, b1, st, 3);
+        multiply(a0, b0);
+        fetch(a0, b0, tk_lds + nxt * STAGE, 0);   // (after the last tile: a stage nobody writes any more)
+        multiply(a1, b1);
+        cur = nxt;
+    }
+    // slab: lane = row m of the tile, registers = columns n0 .. n0+3
+    float *slab = g.ws + (long long)z * g.M * g.ws_ld;
+#pragma unroll
+    for (int i = 0; i < TK_T; ++i) {
+        const int m = (mt0 + i) * 16 + jl;
+        if (mt0 + i < own_m || m >= g.M) continue;
+#pragma unroll
+        for (int j = 0; j < TK_T; ++j) {
+            const int n0 = n_lo + (nt0 + j) * 16 + 4 * kq;
+            if (nt0 + j >= own_n && nt0 + j < ntn && n0 < g.ws_ld)
+                *reinterpret_cast<float4 *>(slab + (long long)m * g.ws_ld + n0) =
+                    make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        }
+    }
+}
+
+constexpr int TALLK_MIN_K = 16384;   // below this the panel kernel's split-K does as well
+
+// K chunks of the tall-K kernel: one workgroup per CU when K allows it (two workgroups per chunk when
+// the output has more than 160 columns), at least 8 k-tiles each
+int tallk_split(int K, int n_ext) {
+    const int cap = n_ext > TK_HALF ? 128 : 256;
+    int s = K / (8 * TK_BK);
+    return s < 1 ? 1 : (s > cap ? cap : s);
 }
 
 template <int TN, int BK>
@@ -615,9 +827,13 @@ bool vec_ok(const float *p, long long s_major) {
 }  // namespace
 
 extern "C" size_t psvae_gemm_f32_workspace_bytes(int M, int N, int K, int split_k) {
+    if (M <= 0 || N <= 0) return 0;
+    size_t tall = 0;   // the tall-K kernel may take the product (decided from the strides at the call)
+    if (split_k == 0 && M <= TK_MAX && N + 1 <= TK_MAX && K >= TALLK_MIN_K)
+        tall = (size_t)tallk_split(K, N + 1) * (size_t)M * (size_t)(N + 4) * sizeof(float);
     split_k = resolve_split(M, N, K, split_k);
-    if (split_k <= 1 || M <= 0 || N <= 0) return 0;
-    return (size_t)split_k * (size_t)M * (size_t)(N + 4) * sizeof(float);
+    const size_t panel = split_k <= 1 ? 0 : (size_t)split_k * (size_t)M * (size_t)(N + 4) * sizeof(float);
+    return tall > panel ? tall : panel;
 }
 
 extern "C" int psvae_gemm_f32(int M, int N, int K, const float *A, const float *amask, int64_t sa_m,
@@ -630,6 +846,39 @@ extern "C" int psvae_gemm_f32(int M, int N, int K, const float *A, const float *
                   "psvae_gemm_f32: null operand");
     PSVAE_REQUIRE(ldc >= N, PSVAE_EINVAL, "psvae_gemm_f32: ldc %lld < N %d", (long long)ldc, N);
     PSVAE_REQUIRE(act == PSVAE_ACT_NONE || act == PSVAE_ACT_RELU, PSVAE_EINVAL, "psvae_gemm_f32: bad act %d", act);
+    hipStream_t s = (hipStream_t)stream;
+    const int n_ext0 = N + (rowsum ? 1 : 0);
+    if (split_k == 0 && sa_m == 1 && sb_n == 1 && amask == nullptr && M <= TK_MAX && n_ext0 <= TK_MAX &&
+        K >= TALLK_MIN_K && M % 4 == 0 && N % 4 == 0 && sa_k % 4 == 0 && sb_k % 4 == 0 && sa_k >= M && sb_k >= N &&
+        psvae_aligned16(A) && psvae_aligned16(B) && psvae_aligned16(workspace)) {
+        const int split = tallk_split(K, n_ext0);
+        GemmArgs g;
+        g.M = M, g.N = N, g.K = K, g.n_ext = n_ext0, g.ws_ld = (n_ext0 + 3) / 4 * 4;
+        PSVAE_REQUIRE(workspace != nullptr &&
+                          workspace_bytes >= (size_t)split * (size_t)M * (size_t)g.ws_ld * sizeof(float),
+                      PSVAE_EWORKSPACE, "psvae_gemm_f32: workspace too small for the tall-K product");
+        g.A = A, g.amask = nullptr, g.sa_m = sa_m, g.sa_k = sa_k, g.B = B, g.sb_k = sb_k, g.sb_n = sb_n;
+        g.C = C, g.ldc = ldc, g.bias = bias, g.rowsum = rowsum, g.cmask = cmask, g.act = act, g.accumulate = accumulate;
+        g.split_k = split, g.ws = (float *)workspace, g.c_vec = 0, g.nt_m = g.nt_n = 1, g.bn = 0, g.wn = 1;
+        g.tail_begin = K / TK_BK * TK_BK;   // the kernel takes whole k-tiles, the reduce kernel the rows left over
+        g.k_chunk = psvae_cdiv(psvae_cdiv(g.tail_begin, split), TK_BK) * TK_BK;
+        g.split_k = psvae_cdiv(g.tail_begin, g.k_chunk);
+        const int halves = n_ext0 > TK_HALF ? 2 : 1;
+        TallKArgs t{M, N, g.tail_begin, n_ext0, A, (long long)sa_k, B, (long long)sb_k, g.ws, g.ws_ld, g.k_chunk, halves, g.split_k};
+        const size_t lds = (size_t)TK_STAGES * TK_BK * (TK_LDA + TK_LDB) * sizeof(float);
+        static bool attr_set = false;   // 92 160 bytes of dynamic LDS: above the default limit
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void *)gemm_tallk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+        // with two halves the chunk count is padded to a multiple of 8 (blocks b, b + 8 pair up)
+        const int chunks_launched = halves == 2 ? psvae_cdiv(g.split_k, 8) * 8 : g.split_k;
+        hipLaunchKernelGGL(gemm_tallk_kernel, dim3(chunks_launched * halves), dim3(TK_THREADS), lds, s, t);
+        PSVAE_CHECK_LAUNCH("psvae_gemm_f32 (tall-K)");
+        launch_splitk_reduce(g, s);
+        PSVAE_CHECK_LAUNCH("psvae_gemm_f32 (tall-K reduce)");
+        return PSVAE_OK;
+    }
     split_k = resolve_split(M, N, K, split_k);
     int k_chunk = psvae_cdiv(psvae_cdiv(K, split_k), 32) * 32;
     if (k_chunk == 0) k_chunk = 32;
@@ -648,9 +897,8 @@ extern "C" int psvae_gemm_f32(int M, int N, int K, const float *A, const float *
     g.A = A, g.amask = amask, g.sa_m = sa_m, g.sa_k = sa_k;
     g.B = B, g.sb_k = sb_k, g.sb_n = sb_n;
     g.C = C, g.ldc = ldc, g.bias = bias, g.rowsum = rowsum, g.cmask = cmask, g.act = act;
-    g.accumulate = accumulate, g.split_k = split_k, g.k_chunk = k_chunk, g.ws = (float *)workspace;
+    g.accumulate = accumulate, g.split_k = split_k, g.k_chunk = k_chunk, g.ws = (float *)workspace, g.tail_begin = K;
     const bool a_kc = (sa_k == 1), b_kc = (sb_k == 1);
-    hipStream_t s = (hipStream_t)stream;
 
     // The panel kernel needs unit stride along one axis of each operand, 16-byte aligned
     // bases / major strides, and the vectorised extent to be a multiple of 4.
@@ -702,9 +950,7 @@ extern "C" int psvae_gemm_f32(int M, int N, int K, const float *A, const float *
     }
     PSVAE_CHECK_LAUNCH("psvae_gemm_f32");
     if (split_k > 1) {
-        const long long total = (long long)M * g.ws_ld;
-        const int rb = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(rb), dim3(256), 0, s, g);
+        launch_splitk_reduce(g, s);
         PSVAE_CHECK_LAUNCH("psvae_gemm_f32 (split-K reduce)");
     }
     return PSVAE_OK;

@@ -105,6 +105,33 @@ def test_gemm_rowsum_with_row_major_operands(M, N, K):
         close(rs, base * -1.0 + a.double().sum(1), what='rowsum')
 
 
+@pytest.mark.parametrize('M,N,K,lda,ldb', [(300, 300, 50003, 300, 300), (304, 100, 20000, 304, 100),
+                                           (16, 8, 16400, 16, 8), (300, 300, 33000, 1200, 1200),
+                                           (120, 304, 70000, 120, 304), (300, 300, 1000, 300, 300)])
+def test_gemm_tall_k_weight_gradient(M, N, K, lda, ldb):
+    """dW = dY^T X (+ db from the same pass) with a small output and a very long contraction:
+    the tall-K kernel (whole output per workgroup, operands straight to LDS) where it applies,
+    the panel kernel for the short case; row-strided operands (slots of a wider matrix), a K
+    that is no multiple of the k-tile, accumulate and a gate on the result."""
+    from ps_vae_amd import hip
+    d = dev()
+    g = torch.Generator().manual_seed(M + N + K)
+    dy = torch.randn(K, lda, generator=g)
+    x = torch.randn(K, ldb, generator=g)
+    want = dy[:, :M].double().t() @ x[:, :N].double()
+    dyd, xd = dy.to(d), x.to(d)
+    gw = torch.full((M, N), 2.0, device=d)
+    gb = torch.full((M,), -1.0, device=d)
+    hip.gemm(M, N, K, dyd, 1, lda, xd, ldb, 1, gw, N, split_k=0, rowsum=gb, accumulate=True)
+    close(gw, 2.0 + want, what='dW (+=)')
+    close(gb, -1.0 + dy[:, :M].double().sum(0), what='db (+=)')
+    gw2 = torch.empty(M, N, device=d)
+    bias = torch.randn(N, generator=g)
+    gate = torch.randn(M, N, generator=g)
+    hip.gemm(M, N, K, dyd, 1, lda, xd, ldb, 1, gw2, N, split_k=0, bias=bias.to(d), relu=True, cmask=gate.to(d))
+    close(gw2, torch.relu(want + bias.double()) * (gate > 0), what='relu(dW + b) gated')
+
+
 def test_gemm_large_split_k():
     from ps_vae_amd import hip
     d = dev()
