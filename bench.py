@@ -236,8 +236,7 @@ def main():
         ids = rng.choice(len(dataset), size=B, replace=False)
         batch = dataset.collate_ids(ids)
         opt.zero_grad()
-        loss = model.training_step(batch, 0)
-        loss.backward()
+        model.training_step(batch, 0).backward()
         opt.step()
         model.global_step += 1
         return batch

@@ -69,14 +69,16 @@ class VAEPieceDecoder(nn.Module):
                              self.piece_embedding.weight, self.pos_embedding.weight)
         return out.view(*shape, out.shape[-1])
 
-    def piece_logits(self, z_vecs, pieces):
-        """:81-90 — teacher-forced GRU over the piece sequence, initial state from z."""
+    def piece_logits(self, z_vecs, pieces, piece_table=None):
+        """:81-90 — teacher-forced GRU over the piece sequence, initial state from z.
+        piece_table: self.piece_embedding.weight as the caller wants it seen by autograd (the
+        two-stream schedule hands it over from the main stream)."""
         rnn = self.rnn
         init_hidden = run_linear(self.latent_to_rnn_hidden, z_vecs)
         if rnn.num_layers == 1 and not rnn.bidirectional and rnn.bias:
             # time-major ids -> [T,B,E] embeddings -> HIP GRU; logits returned batch-major
             ids = pieces[:, :-1].t().contiguous().to(torch.int32)
-            table = self.piece_embedding.weight
+            table = self.piece_embedding.weight if piece_table is None else piece_table
             emb = ops.embedding(ids, table) if table.shape[1] % 4 == 0 else self.piece_embedding(ids.long())
             hs = ops.gru(emb, init_hidden, rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.bias_ih_l0, rnn.bias_hh_l0)
             return run_linear(self.to_vocab, hs).transpose(0, 1)
@@ -132,6 +134,8 @@ class VAEPieceDecoder(nn.Module):
         side = _SIDE_STREAMS.get(node_x.device)
         if side is None:
             side = _SIDE_STREAMS[node_x.device] = torch.cuda.Stream(node_x.device)
+        if ids is not None:
+            node_x = ids.for_side_stream()   # the embedding tables are shared with the main-stream encoder
         side.wait_stream(main)
         with torch.cuda.stream(side):
             node_embedding, _ = self.graph_embedding.embed_node(node_x, csr, None)
@@ -148,8 +152,8 @@ class VAEPieceDecoder(nn.Module):
         gold_piece = pieces[:, 1:].flatten()
         side = node_embedding[1] if node_embedding is not None else None
 
-        def piece_branch():
-            output = self.piece_logits(z_vecs, pieces)
+        def piece_branch(piece_table=None):
+            output = self.piece_logits(z_vecs, pieces, piece_table)
             pred_piece = output.reshape(-1, output.shape[-1])
             return pred_piece, self.piece_loss(pred_piece, gold_piece)
 
@@ -161,9 +165,11 @@ class VAEPieceDecoder(nn.Module):
             node_embedding = node_embedding[0]
             main.wait_stream(side)                  # node_embedding is complete
             node_embedding.record_stream(main)
+            # the piece table also feeds the atom features of the main-stream encoder
+            piece_table = ops.stream_handoff(self.piece_embedding.weight)
             side.wait_stream(main)                  # z_vecs is complete
             with torch.cuda.stream(side):
-                pred_piece, piece_loss = piece_branch()
+                pred_piece, piece_loss = piece_branch(piece_table)
             for t in (z_vecs, pieces, gold_piece):
                 t.record_stream(side)
         else:

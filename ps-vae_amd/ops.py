@@ -352,6 +352,23 @@ def embedding(ids, table):
 
 
 # ------------------------------------------------------------------------ first encoder layer on ids
+class _StreamHandoff(Function):
+    """Identity whose backward runs on the stream its forward was called on."""
+
+    @staticmethod
+    def forward(ctx, t):
+        return t.view_as(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def stream_handoff(t):
+    """t for use on another stream: gradients come back onto the stream current at this call."""
+    return _StreamHandoff.apply(t) if t.requires_grad and torch.is_grad_enabled() else t
+
+
 class EmbeddedIds:
     """The atoms of a batch as embedding ids plus the three tables, standing for the rows
     embed_atom would produce (src/modules/vae_piece_decoder.py:65-69).  Encoder.embed_node
@@ -372,6 +389,16 @@ class EmbeddedIds:
     def rows(self):
         """The embedded rows themselves, [V, D]."""
         return embed_atom(self.x, self.xp, self.xq, *self.tables)
+
+    def for_side_stream(self):
+        """The same ids with the tables passed through an identity node made HERE, on the current
+        stream.  A chain that then uses the result on another stream sends its table gradients
+        back through that node, i.e. onto this stream, where the tables' other users and their
+        gradient accumulators live (autograd joins the two streams at the node)."""
+        twin = EmbeddedIds(self.x, self.xp, self.xq, *(stream_handoff(t) for t in self.tables))
+        if getattr(self, '_indicator', None) is not None:
+            twin._indicator = self._indicator
+        return twin
 
     def tensors(self):
         """Every device buffer this object owns (for record_stream on a second stream)."""

@@ -9,7 +9,6 @@ forward() takes either the reference's batch dict (any source) or a CollatedBatc
 the kernels read the CSR / pair lists collation wrote."""
 import os
 import time
-import warnings
 
 import torch
 import torch.nn as nn
@@ -38,17 +37,16 @@ class PSVAEModel(nn.Module):
         # compact path only; PSVAE_STREAMS=1 keeps everything on the current stream
         self.two_streams = os.environ.get('PSVAE_STREAMS', '2') != '1'
         self.two_streams_min_nodes = 32768   # atoms in the batch from which the fork pays (measured)
-        if self.two_streams:
-            # parameters of the side-stream chain receive their gradients on that stream; autograd
-            # orders the accumulation correctly and says so once per process
-            warnings.filterwarnings('ignore', message="The AccumulateGrad node's stream does not match")
 
     @property
     def device(self):
         return next(self.parameters()).device
 
     def log(self, name, value, **kwargs):
-        self.logged[name] = value
+        # detached, like Lightning's self.log: a logged loss must not keep the step's autograd graph
+        # (and with it the parameters' gradient accumulators, which remember the stream they were
+        # created under) alive into the next step
+        self.logged[name] = value.detach() if torch.is_tensor(value) else value
 
     def forward(self, batch, return_accu=False, eps=None):
         compact = getattr(batch, 'compact', None)

@@ -133,6 +133,7 @@ def fit(model, train_loader, valid_loader=None, test_loader=None, max_epochs=6, 
             opt.zero_grad()
             loss = model.training_step(batch, i)
             loss.backward()
+            loss = loss.detach()   # the graph must be gone before the next forward builds its own
             if not fused_tail and grad_clip:
                 torch.nn.utils.clip_grad_norm_(model.parameters(), grad_clip)
             opt.step()

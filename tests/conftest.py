@@ -13,6 +13,12 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # Multi-rank GPU tests start their ranks from a fork server.  It has to exist before any test
+    # initialises the GPU in this process: from then on this process must not exec another program.
+    import multiprocessing
+    from multiprocessing import forkserver
+    multiprocessing.set_forkserver_preload([])
+    forkserver.ensure_running()
 
 
 class Tokenizer:
