@@ -1,0 +1,373 @@
+// The panel kernel of psvae_gemm_f32 (see gemm.hip for the overview) and its launcher template.
+#pragma once
+#include "gemm_common.h"
+
+namespace psvae_gemm {
+
+// ------------------------------------------------------------------------------------------
+// Fast path: 128 x (32*TN) panel per workgroup, vector loads.
+// ------------------------------------------------------------------------------------------
+template <int BX, int BK, bool KCONTIG>
+struct TileLoader {
+    static constexpr int ITEMS = BX * BK / 4;                         // float4 items per tile
+    static constexpr int PER_THREAD = (ITEMS + THREADS - 1) / THREADS;
+    static constexpr int STRIDE = KCONTIG ? BX + 1 : BX + 4;          // LDS row stride (floats)
+
+    // element (x, k) of the operand lives at p[x*sx + k*sk]; KCONTIG: sk == 1, else sx == 1.
+    // MASK: the element counts as 0 where pm[same offset] <= 0.  ONES: a virtual column of
+    // ones at x == ones_x (only for !KCONTIG).
+    //
+    // load() ONLY issues the global loads (unconditionally, from a clamped address) and
+    // store() applies bounds / mask / ones while writing LDS one k-tile later.  Anything that
+    // consumes a loaded value before the MFMA loop — or a branch around a load — makes the
+    // compiler wait for the loads right there and the prefetch no longer overlaps the MFMAs.
+    struct Coord {
+        int x, k;
+        bool in_tile;
+    };
+    __device__ static __forceinline__ Coord coord(int i, int tid, int x0, int k0) {
+        const int item = tid + THREADS * i;
+        Coord c;
+        if (KCONTIG) {
+            c.x = x0 + item / (BK / 4), c.k = k0 + 4 * (item % (BK / 4));
+        } else {
+            c.x = x0 + 4 * (item % (BX / 4)), c.k = k0 + item / (BX / 4);
+        }
+        c.in_tile = (ITEMS % THREADS == 0) || item < ITEMS;
+        return c;
+    }
+
+    template <bool MASK>
+    __device__ static __forceinline__ void load(float4 (&r)[PER_THREAD], float4 (&rm)[MASK ? PER_THREAD : 1],
+                                                const float *__restrict__ p, const float *__restrict__ pm,
+                                                long long sx, long long sk, int x0, int k0, int X, int k_end,
+                                                int tid) {
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) {
+            const Coord c = coord(i, tid, x0, k0);
+            const bool ok = c.in_tile && c.x < X && c.k < k_end;
+            const long long off = ok ? (KCONTIG ? (long long)c.x * sx + c.k : (long long)c.k * sk + c.x) : 0;
+            r[i] = *reinterpret_cast<const float4 *>(p + off);
+            if (MASK) rm[i] = *reinterpret_cast<const float4 *>(pm + off);
+        }
+    }
+
+    // INTERIOR: the whole tile lies inside the operand (no bounds to apply, no ones column): the
+    // staging then costs its LDS writes only, which matters because vector instructions beside
+    // other waves' MFMA loops issue several times slower than alone.
+    template <bool MASK, bool ONES, bool INTERIOR = false>
+    __device__ static __forceinline__ void store(float *T, const float4 (&r)[PER_THREAD],
+                                                 const float4 (&rm)[MASK ? PER_THREAD : 1], int x0, int k0, int X,
+                                                 int k_end, int ones_x, int tid) {
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i) {
+            const Coord c = coord(i, tid, x0, k0);
+            if (!c.in_tile) continue;
+            const bool ok = INTERIOR || (c.x < X && c.k < k_end);
+            float4 v = r[i];
+            if (MASK) {
+                const float4 m = rm[i];
+                v.x = m.x > 0.f ? v.x : 0.f, v.y = m.y > 0.f ? v.y : 0.f;
+                v.z = m.z > 0.f ? v.z : 0.f, v.w = m.w > 0.f ? v.w : 0.f;
+            }
+            v.x = ok ? v.x : 0.f, v.y = ok ? v.y : 0.f, v.z = ok ? v.z : 0.f, v.w = ok ? v.w : 0.f;
+            if (ONES && !KCONTIG && !INTERIOR) v.x = (c.k < k_end && c.x == ones_x) ? 1.f : v.x;
+            const int item = tid + THREADS * i;
+            if (KCONTIG) {
+                const int kq = item % (BK / 4), x = item / (BK / 4);
+                float *d = T + (4 * kq) * STRIDE + x;
+                d[0] = v.x, d[STRIDE] = v.y, d[2 * STRIDE] = v.z, d[3 * STRIDE] = v.w;
+            } else {
+                const int xq = item % (BX / 4), k = item / (BX / 4);
+                *reinterpret_cast<float4 *>(T + k * STRIDE + 4 * xq) = v;
+            }
+        }
+    }
+};
+
+// WN = 1: the 4 waves stack along M (128-row panel, 32*TN columns).  WN = 2: a 2 x 2 wave grid
+// (64 rows x 64*TN columns), for products whose M fits 64-row panels with less padding.
+template <int TN, int BK, bool A_KC, bool B_KC, bool MASK, bool ONES, int WN = 1>
+__global__ __launch_bounds__(THREADS, (MASK || WN > 1 || TN > 5) ? 2 : PSVAE_PANEL_OCC) void gemm_panel_kernel(GemmArgs g) {
+    constexpr int WM = 4 / WN, BM = 32 * WM, BN = 32 * TN * WN;
+    using LA = TileLoader<BM, BK, A_KC>;
+    using LB = TileLoader<BN, BK, B_KC>;
+    constexpr int A_FLOATS = BK * LA::STRIDE, B_FLOATS = BK * LB::STRIDE;
+    constexpr int STAGE_FLOATS = A_FLOATS + B_FLOATS;
+    // two LDS stages where two workgroups of them still fit a CU's 160 KiB
+    constexpr int NBUF = (PSVAE_PANEL_NBUF == 2 && 2 * STAGE_FLOATS * 4 <= 76 * 1024) ? 2 : 1;
+    constexpr int EPI_STRIDE = 36, EPI_FLOATS = 4 * 32 * EPI_STRIDE;   // one 32x32 tile per wave
+    constexpr int LDS_FLOATS = NBUF * STAGE_FLOATS > EPI_FLOATS ? NBUF * STAGE_FLOATS : EPI_FLOATS;
+    __shared__ __align__(16) float smem[LDS_FLOATS];
+    float *As = smem, *Bs = smem + A_FLOATS;
+
+    int tile_m, tile_n, z;
+    if (!tile_of_block(g, tile_m, tile_n, z)) return;
+    const int m0 = tile_m * BM, n0 = tile_n * g.bn;
+    const int k_begin = z * g.k_chunk;
+    const int k_end = min(g.K, k_begin + g.k_chunk);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_m = wave % WM, wave_n = wave / WM;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int ones_x = g.N;
+    const int n_lim = min(g.N, n0 + g.bn);   // columns of B this tile may read
+    // accumulator tiles of this wave that hold at least one real column (wave-uniform)
+    const int tn_live = (min(g.n_ext, n0 + g.bn) - n0 - wave_n * TN * 32 + 31) >> 5;
+
+    f32x16 acc[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    float4 ra[LA::PER_THREAD], rb[LB::PER_THREAD], rma[MASK ? LA::PER_THREAD : 1], rmb[1];
+    if (k_begin < k_end) {
+        LA::template load<MASK>(ra, rma, g.A, g.amask, g.sa_m, g.sa_k, m0, k_begin, g.M, k_end, tid);
+        LB::template load<false>(rb, rmb, g.B, nullptr, g.sb_n, g.sb_k, n0, k_begin, n_lim, k_end, tid);
+    }
+    // operand tiles without an edge in x (rows of A / columns of B incl. the ones column)
+    const bool a_inside = m0 + BM <= g.M, b_inside = n0 + BN <= n_lim;
+    const float *a_rd = As + lhi * LA::STRIDE + wave_m * 32 + l31;
+    const float *b_rd = Bs + lhi * LB::STRIDE + wave_n * TN * 32 + l31;
+
+    // registers -> LDS stage `buf` for the k-tile that starts at k0
+    auto stage = [&](int buf, int k0) {
+        float *as = As + buf * STAGE_FLOATS, *bs = Bs + buf * STAGE_FLOATS;
+        if (k0 + BK <= k_end && a_inside)   // wave-uniform
+            LA::template store<MASK, false, true>(as, ra, rma, m0, k0, g.M, k_end, -1, tid);
+        else
+            LA::template store<MASK, false>(as, ra, rma, m0, k0, g.M, k_end, -1, tid);
+        if (k0 + BK <= k_end && b_inside)
+            LB::template store<false, ONES, true>(bs, rb, rmb, n0, k0, n_lim, k_end, ones_x, tid);
+        else
+            LB::template store<false, ONES>(bs, rb, rmb, n0, k0, n_lim, k_end, ones_x, tid);
+    };
+    // the MFMAs of one k-tile from stage `buf`: operand registers for k-step s+1 are fetched from
+    // LDS while the MFMAs of step s run; the scheduling barriers keep the compiler from sinking the
+    // reads next to their use
+    auto multiply = [&](int buf, int k0) {
+        const float *ar = a_rd + buf * STAGE_FLOATS, *br = b_rd + buf * STAGE_FLOATS;
+        float a_cur = ar[0], b_cur[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b_cur[j] = br[j * 32];
+        const int k_live = k_end - k0;   // the last k-tile of a chunk may be partly empty
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            if (kk > 0 && kk >= k_live) break;   // wave-uniform
+            float a_nxt = 0.f, b_nxt[TN];
+            if (kk + 2 < BK) {
+                a_nxt = ar[(kk + 2) * LA::STRIDE];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b_nxt[j] = br[(kk + 2) * LB::STRIDE + j * 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                // the last column tile of a wide product may leave up to two tiles empty (N = 328 as
+                // 2 x 192, 600 as 3 x 224); tiles of 5 or fewer never do for this model's widths
+                if (TN < 6 || j + 2 < TN || j < tn_live)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur[j], acc[j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk + 2 < BK) {
+                a_cur = a_nxt;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b_cur[j] = b_nxt[j];
+            }
+        }
+    };
+    if constexpr (NBUF == 1) {
+        // one LDS stage: write it, barrier, request the next k-tile, multiply, barrier
+        for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+            stage(0, k0);
+            __syncthreads();
+            if (k0 + BK < k_end) {
+                LA::template load<MASK>(ra, rma, g.A, g.amask, g.sa_m, g.sa_k, m0, k0 + BK, g.M, k_end, tid);
+                LB::template load<false>(rb, rmb, g.B, nullptr, g.sb_n, g.sb_k, n0, k0 + BK, n_lim, k_end, tid);
+            }
+            multiply(0, k0);
+            __syncthreads();
+        }
+    } else {
+        // two LDS stages: the next k-tile is requested before the current one is multiplied and
+        // written to the other stage right after, so a k-tile costs ONE barrier and the staging
+        // stores of a wave run beside the other waves' MFMAs
+        if (k_begin < k_end) stage(0, k_begin);
+        __syncthreads();
+        int cur = 0;
+        for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+            const bool more = k0 + BK < k_end;   // block-uniform
+            if (more) {
+                LA::template load<MASK>(ra, rma, g.A, g.amask, g.sa_m, g.sa_k, m0, k0 + BK, g.M, k_end, tid);
+                LB::template load<false>(rb, rmb, g.B, nullptr, g.sb_n, g.sb_k, n0, k0 + BK, n_lim, k_end, tid);
+            }
+            multiply(cur, k0);
+            if (more) stage(cur ^ 1, k0 + BK);
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+
+    // Epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) +
+    // 4 * (lane >> 5): a direct store would be 16 dword stores per tile, each touching two
+    // 128-B row segments.  Instead every wave transposes one tile at a time through its own
+    // 32 x 36 LDS patch and writes float4 per lane: 4 store instructions of 8 rows x 128 B.
+    const int col_lim = min(g.n_ext, n0 + g.bn);
+    const bool split = g.split_k > 1;
+    float *out = split ? g.ws + (long long)z * g.M * g.ws_ld : g.C;
+    const long long ld = split ? g.ws_ld : g.ldc;
+    if (g.c_vec) {
+        // A wait for a load also waits for every store issued before it (one in-order counter), and a
+        // store takes microseconds to be acknowledged while the chip is writing C.  So every
+        // value the epilogue reads from memory is requested BEFORE the stores it would queue
+        // behind: all bias vectors ahead of the first store, and a tile's old C / gate rows ahead
+        // of that tile's stores.  The empty asm statements consume the loaded registers, which
+        // pins the wait to that point instead of one wait per store further down.
+        float *patch = smem + wave * 32 * EPI_STRIDE;
+        const int prow = lane >> 3, pc4 = (lane & 7) * 4;
+        const bool use_bias = !split && g.bias != nullptr;
+        const bool use_old = !split && g.accumulate, use_gate = !split && g.cmask != nullptr;
+        float4 bias4[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + (wave_n * TN + j) * 32 + pc4;
+            bias4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (use_bias && col < g.N) bias4[j] = *reinterpret_cast<const float4 *>(g.bias + col);
+        }
+        if (use_bias) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                asm volatile("" : "+v"(bias4[j].x), "+v"(bias4[j].y), "+v"(bias4[j].z), "+v"(bias4[j].w));
+        }
+        // Instructions of a wave that shares its SIMD with MFMA loops issue an order of magnitude
+        // slower than alone (stamps: 0.16 us for a tile's LDS transposition, 1.3-2 us for the ~160
+        // vector instructions around its four stores), so the common case - a tile that lies fully
+        // inside C - runs on row pointers computed once, immediate column offsets and no bounds tests.
+        const bool rows_full = g.c_vec == 2 && m0 + wave_m * 32 + 32 <= g.M;
+        unsigned ro[4];   // byte offsets of this lane's four rows (c_vec == 2: they fit 32 bits)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            ro[i] = rows_full ? (unsigned)(((long long)(m0 + wave_m * 32 + prow + 8 * i) * ld + n0 + wave_n * TN * 32 + pc4) * 4)
+                              : 0u;
+        char *out_b = reinterpret_cast<char *>(out);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int cbase = n0 + (wave_n * TN + j) * 32;
+            if (cbase >= col_lim) continue;   // wave-uniform
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                patch[((r & 3) + 8 * (r >> 2) + 4 * lhi) * EPI_STRIDE + l31] = acc[j][r];
+            if (rows_full && !use_old && !use_gate && cbase + 32 <= g.N) {   // wave-uniform: the whole tile is inside C
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const float4 b4 = bias4[j];
+                const float inf = __builtin_inff();
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float4 v = *reinterpret_cast<const float4 *>(patch + (prow + 8 * i) * EPI_STRIDE + pc4);
+                    if (!split) {
+                        v.x += b4.x, v.y += b4.y, v.z += b4.z, v.w += b4.w;
+                        if (g.act == PSVAE_ACT_RELU)   // one v_med3_f32 per element
+                            v.x = __builtin_amdgcn_fmed3f(v.x, 0.f, inf), v.y = __builtin_amdgcn_fmed3f(v.y, 0.f, inf),
+                            v.z = __builtin_amdgcn_fmed3f(v.z, 0.f, inf), v.w = __builtin_amdgcn_fmed3f(v.w, 0.f, inf);
+                    }
+                    *reinterpret_cast<float4 *>(out_b + ro[i] + 128 * j) = v;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // patch is rewritten by the next tile
+                continue;
+            }
+            const int col = cbase + pc4;
+            float4 old4[4], gate4[4];
+            if (use_old || use_gate) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = m0 + wave_m * 32 + prow + 8 * i;
+                    const bool in = row < g.M && col < g.N;
+                    const long long off = in ? (long long)row * ld + col : 0;
+                    old4[i] = gate4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (use_old) old4[i] = *reinterpret_cast<const float4 *>(out + off);
+                    if (use_gate) gate4[i] = *reinterpret_cast<const float4 *>(g.cmask + off);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    asm volatile("" : "+v"(old4[i].x), "+v"(old4[i].y), "+v"(old4[i].z), "+v"(old4[i].w));
+                    asm volatile("" : "+v"(gate4[i].x), "+v"(gate4[i].y), "+v"(gate4[i].z), "+v"(gate4[i].w));
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = m0 + wave_m * 32 + prow + 8 * i;
+                float4 v = *reinterpret_cast<const float4 *>(patch + (prow + 8 * i) * EPI_STRIDE + pc4);
+                if (row >= g.M || col >= col_lim) continue;
+                if (split) {
+                    *reinterpret_cast<float4 *>(out + (long long)row * ld + col) = v;
+                } else if (col == g.N) {          // the virtual ones column (N % 4 == 0 here)
+                    float *rs = g.rowsum + row;
+                    *rs = g.accumulate ? *rs + v.x : v.x;
+                } else {
+                    const float4 b4 = bias4[j];
+                    v.x += b4.x, v.y += b4.y, v.z += b4.z, v.w += b4.w;
+                    if (g.act == PSVAE_ACT_RELU)
+                        v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+                    if (use_old) {
+                        const float4 o = old4[i];
+                        v.x += o.x, v.y += o.y, v.z += o.z, v.w += o.w;
+                    }
+                    if (use_gate) {
+                        const float4 mk = gate4[i];
+                        v.x = mk.x > 0.f ? v.x : 0.f, v.y = mk.y > 0.f ? v.y : 0.f;
+                        v.z = mk.z > 0.f ? v.z : 0.f, v.w = mk.w > 0.f ? v.w : 0.f;
+                    }
+                    *reinterpret_cast<float4 *>(out + (long long)row * ld + col) = v;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // patch is rewritten by the next tile
+        }
+    } else {
+        const int row0 = m0 + wave_m * 32 + 4 * lhi;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + (wave_n * TN + j) * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + (r & 3) + 8 * (r >> 2);
+                if (col < col_lim && row < g.M) store_result(g, z, row, col, acc[j][r]);
+            }
+        }
+    }
+}
+
+template <int TN, int BK>
+void launch_panel(const GemmArgs &g, bool a_kc, bool b_kc, dim3 grid, hipStream_t s) {
+    const bool mask = g.amask != nullptr, ones = g.rowsum != nullptr;
+    const dim3 blk(THREADS);
+#define PSVAE_PANEL(AKC, BKC, MASK, ONES) \
+    hipLaunchKernelGGL((gemm_panel_kernel<TN, BK, AKC, BKC, MASK, ONES>), grid, blk, 0, s, g)
+    if (a_kc && b_kc) {                 // forward X W^T
+        if (mask) PSVAE_PANEL(true, true, true, false); else PSVAE_PANEL(true, true, false, false);
+    } else if (a_kc) {                  // input gradient dY W (rowsum: the ones column of the n-contiguous B)
+        if (mask && ones) PSVAE_PANEL(true, false, true, true);
+        else if (mask) PSVAE_PANEL(true, false, true, false);
+        else if (ones) PSVAE_PANEL(true, false, false, true);
+        else PSVAE_PANEL(true, false, false, false);
+    } else if (b_kc) {
+        if (mask) PSVAE_PANEL(false, true, true, false); else PSVAE_PANEL(false, true, false, false);
+    } else if (g.wn == 2) {             // the same on the 2 x 2 wave grid (TN == 5 only)
+        if constexpr (TN == 5) {
+#define PSVAE_PANEL22(MASK, ONES) \
+    hipLaunchKernelGGL((gemm_panel_kernel<5, BK, false, false, MASK, ONES, 2>), grid, blk, 0, s, g)
+            if (mask && ones) PSVAE_PANEL22(true, true);
+            else if (mask) PSVAE_PANEL22(true, false);
+            else if (ones) PSVAE_PANEL22(false, true);
+            else PSVAE_PANEL22(false, false);
+#undef PSVAE_PANEL22
+        }
+    } else {                            // weight (+ bias) gradient dY^T [X | 1]
+        if (mask && ones) PSVAE_PANEL(false, false, true, true);
+        else if (mask) PSVAE_PANEL(false, false, true, false);
+        else if (ones) PSVAE_PANEL(false, false, false, true);
+        else PSVAE_PANEL(false, false, false, false);
+    }
+#undef PSVAE_PANEL
+}
+
+}  // namespace psvae_gemm

@@ -42,6 +42,7 @@ class CompactBatch:
                 event.synchronize()
                 P = int(host[0])
                 self._pending = None
+                _PINNED_FREE.append(host)      # the staging buffer is free for the next batch
             src, dst, graph, gold = (b[:P] for b in self._pair_bufs)
             self._pairs = ops.PairList(src, dst, graph, self.pair_off, self.segments)
             self._golden = gold
@@ -61,18 +62,15 @@ class CompactBatch:
         return self.cx.numel()
 
 
-_PINNED = {'ring': [], 'next': 0}
+_PINNED_FREE = []
 
 
 def _pinned_int():
-    """One of a small ring of pinned int32[1] host buffers (a batch holds its buffer only
-    until the pair count has been read, long before the ring wraps)."""
-    ring = _PINNED['ring']
-    if len(ring) < 16:
-        ring.append(torch.empty(1, dtype=torch.int32).pin_memory())
-        return ring[-1]
-    _PINNED['next'] = (_PINNED['next'] + 1) % len(ring)
-    return ring[_PINNED['next']]
+    """A pinned int32[1] host buffer that belongs to ONE batch until its pair count has been
+    read (CompactBatch._resolve hands it back): however many batches are collated ahead of
+    their use, none of them can read another batch's count.  A batch dropped unread simply
+    keeps its 4 bytes."""
+    return _PINNED_FREE.pop() if _PINNED_FREE else torch.empty(1, dtype=torch.int32).pin_memory()
 
 
 class CollatedBatch(dict):

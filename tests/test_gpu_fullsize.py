@@ -140,5 +140,6 @@ def test_losses_and_gradients_add_over_half_batches(workload, tokenizer):
     for k, g in grads[0].items():
         scale = g.abs().max().item()
         err = (grads[1][k] + grads[2][k] - g).abs().max().item()
-        # identical terms summed in a different order (split-K chunking depends on the row count)
+        # identical terms summed in a different order (the K chunks of a weight-gradient product are
+        # cut from the row count, so the full batch and its halves chain their fp32 partial sums differently)
         assert err <= 2e-5 * scale + 1e-30, f'{k}: {err / max(scale, 1e-30):.2e} of the largest entry'

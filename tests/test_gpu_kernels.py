@@ -132,6 +132,60 @@ def test_gemm_tall_k_weight_gradient(M, N, K, lda, ldb):
     close(gw2, torch.relu(want + bias.double()) * (gate > 0), what='relu(dW + b) gated')
 
 
+@pytest.mark.parametrize('M,N,K,lda,ldc', [(95148, 300, 300, 300, 300), (8192, 320, 16, 16, 320),
+                                           (8269, 164, 44, 44, 164), (20001, 300, 300, 1200, 1200),
+                                           (33000, 200, 1200, 1200, 200), (70000, 300, 20, 20, 300)])
+def test_gemm_tall_narrow_products(M, N, K, lda, ldc):
+    """Tall products with k-contiguous operands and a narrow output (the per-node Linear layers of
+    the benchmark batch): forward with bias and ReLU, the gated and the accumulating form, ragged
+    last panel / last k-tile, row-strided A and C, repeats bit for bit."""
+    from ps_vae_amd import hip
+    d = dev()
+    g = torch.Generator(device=d).manual_seed(M + N + K)
+    a = torch.randn(M, lda, device=d, generator=g)
+    w = torch.randn(N, K, device=d, generator=g)
+    b = torch.randn(N, device=d, generator=g)
+    want = a[:, :K].double() @ w.double().t()
+    out = torch.full((M, ldc), 7.0, device=d)
+    hip.gemm(M, N, K, a, lda, 1, w, 1, K, out, ldc, bias=b, relu=True)
+    close(out[:, :N], torch.relu(want + b.double()), what='relu(xW^T+b)')
+    if ldc > N:
+        assert bool((out[:, N:] == 7.0).all()), 'columns beyond N were written'
+    gate = torch.randn(M, ldc, device=d, generator=g)
+    out2 = torch.full((M, ldc), 0.5, device=d)
+    hip.gemm(M, N, K, a, lda, 1, w, 1, K, out2, ldc, cmask=gate, accumulate=True)
+    close(out2[:, :N], (0.5 + want) * (gate[:, :N] > 0), what='gated +=')
+    # repeats are bit-identical (tiles that reach LDS late would show here)
+    again = torch.full((M, ldc), 7.0, device=d)
+    for _ in range(5):
+        hip.gemm(M, N, K, a, lda, 1, w, 1, K, again, ldc, bias=b, relu=True)
+        assert torch.equal(again, out)
+
+
+def test_gemm_tall_k_repeats_bit_for_bit():
+    """The stacked conv-weight gradient of the benchmark (300 x 300 over 380 592 rows) forty times
+    in a row: every result equals the first bit for bit.  The kernel's k-tiles reach LDS through
+    loads that no barrier waits for by itself; a tile read before it has landed shows up as a
+    result that differs by one k-step's products, about 1e-5 of an entry - below what a
+    comparison with float64 notices, so the repeats are compared exactly."""
+    from ps_vae_amd import hip
+    d = dev()
+    K = 380592
+    g = torch.Generator(device=d).manual_seed(77)
+    dy = torch.randn(K, 300, device=d, generator=g)
+    x = torch.randn(K, 300, device=d, generator=g)
+    first = torch.empty(300, 300, device=d)
+    fb = torch.empty(300, device=d)
+    hip.gemm(300, 300, K, dy, 1, 300, x, 300, 1, first, 300, split_k=0, rowsum=fb)
+    close(first, (dy.double().t() @ x.double()), what='dW')
+    outs = [(torch.empty(300, 300, device=d), torch.empty(300, device=d)) for _ in range(40)]
+    for gw, gb in outs:
+        hip.gemm(300, 300, K, dy, 1, 300, x, 300, 1, gw, 300, split_k=0, rowsum=gb)
+    torch.cuda.synchronize()
+    bad = [i for i, (gw, gb) in enumerate(outs) if not (torch.equal(gw, first) and torch.equal(gb, fb))]
+    assert not bad, f'repeats {bad} differ from the first result'
+
+
 def test_gemm_large_split_k():
     from ps_vae_amd import hip
     d = dev()

@@ -1,15 +1,15 @@
 #!/bin/bash
-# A/B build of the library with extra -D flags on gemm.hip / gine.hip (the other objects are
-# reused):  tools/build_variant.sh NAME "-DPSVAE_PANEL_BK=16 ..."  ->  exp_libs/libpsvae_NAME.so
+# A/B build of the library with extra -D flags (every object is rebuilt, in a scratch copy of the
+# sources):  tools/build_variant.sh NAME "-DPSVAE_PANEL_OCC=2 ..."  ->  exp_libs/libpsvae_NAME.so
 set -e
-cd "$(dirname "$0")/../ps-vae_amd/csrc"
-make -j8 >/dev/null
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 NAME=$1; DEFS=$2
-OUT=../../exp_libs; mkdir -p $OUT
-FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function"
-/opt/rocm/bin/hipcc $FLAGS $DEFS -I. -c ${GEMM_SRC:-gemm.hip} -o $OUT/gemm_$NAME.o &
-/opt/rocm/bin/hipcc $FLAGS $DEFS -c gine.hip -o $OUT/gine_$NAME.o &
-wait
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $OUT/gemm_$NAME.o $OUT/gine_$NAME.o collate.o misc.o assemble.o node_embed.o optim.o gru.o -o $OUT/libpsvae_$NAME.so
-rm -f $OUT/gemm_$NAME.o $OUT/gine_$NAME.o
-echo built $OUT/libpsvae_$NAME.so
+TMP=/tmp/psvae_variant_$NAME
+rm -rf $TMP && mkdir -p $TMP/ps-vae_amd $TMP/include
+cp $ROOT/include/*.h $TMP/include/
+mkdir -p $TMP/ps-vae_amd/csrc
+cp $ROOT/ps-vae_amd/csrc/*.hip $ROOT/ps-vae_amd/csrc/*.h $ROOT/ps-vae_amd/csrc/Makefile $TMP/ps-vae_amd/csrc/
+make -C $TMP/ps-vae_amd/csrc -j8 EXTRA="$DEFS" >/dev/null
+mkdir -p $ROOT/exp_libs
+cp $TMP/ps-vae_amd/csrc/libpsvae_hip.so $ROOT/exp_libs/libpsvae_$NAME.so
+echo built $ROOT/exp_libs/libpsvae_$NAME.so
