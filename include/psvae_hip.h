@@ -316,6 +316,21 @@ int psvae_link_ce_bwd_input(int P, int F, int C, const float *dlogits, const flo
                             const float *g_loss, float *g_hid, int ldg, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * Cross-entropy of the piece language model with an ignored label
+ * (nn.CrossEntropyLoss(ignore_index=pad): src/modules/vae_piece_decoder.py:53,113-114):
+ * logits [R,V] rows of stride ld, gold [R]; over the rows with gold != ignore_index
+ *     loss[0] = mean( logsumexp(logits[r]) - logits[r][gold[r]] ),  loss[1] = 1 / #rows
+ * (no such row: NaN, as torch's mean over nothing); dlogits [R,V] (dense) = softmax - onehot, zero
+ * rows where ignored: times g_loss * loss[1] it is the gradient; counts[0] = #rows,
+ * counts[1] = #{r : first argmax == gold[r]} (src/modules/vae_piece_decoder.py:120-122).
+ * V <= 1024.  Sums run in a fixed order.
+ * ---------------------------------------------------------------------------------- */
+size_t psvae_token_ce_workspace_bytes(int R);
+int psvae_token_ce_fwd(int R, int V, const float *logits, int64_t ld, const int32_t *gold, int ignore_index,
+                       float *dlogits, float *loss, int32_t *counts,
+                       void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * Inference link prediction (src/modules/vae_piece_decoder.py:233-240):
  * prob = softmax(logits[p]); conf[p] = max prob, etype[p] = argmax (first maximum);
  * keep[p] = conf[p] >= add_edge_th && etype[p] != none_bond.

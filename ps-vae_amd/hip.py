@@ -58,6 +58,8 @@ _SIGNATURES = {
     'psvae_link_ce_workspace_bytes': (_c_size, [_c_int]),
     'psvae_link_ce_fwd': (_c_int, [_c_int, _c_int, _c_int, _p, _c_int, _p, _p, _p, _p, _p, _p, _p, _p, _c_size, _p]),
     'psvae_link_ce_bwd_input': (_c_int, [_c_int, _c_int, _c_int, _p, _p, _p, _p, _c_int, _p]),
+    'psvae_token_ce_workspace_bytes': (_c_size, [_c_int]),
+    'psvae_token_ce_fwd': (_c_int, [_c_int, _c_int, _p, _c_i64, _p, _c_int, _p, _p, _p, _p, _c_size, _p]),
     'psvae_link_infer': (_c_int, [_c_int, _c_int, _p, _c_f32, _c_int, _p, _p, _p, _p]),
     'psvae_embed_trans_fwd': (_c_int, [_c_int, _c_int, _p, _p, _p, _c_int, _c_int, _c_int, _p, _p, _c_int, _p]),
     'psvae_clip_adam_workspace_bytes': (_c_size, [_c_ll]),
@@ -476,6 +478,18 @@ def link_ce_bwd_input(dlogits, W, g_loss, g_hid):
     pg, ldg = _rows(g_hid) if P else (None, W.shape[1])
     _check(lib().psvae_link_ce_bwd_input(P, W.shape[1], C, ptr(dlogits, torch.float32), ptr(W, torch.float32),
                                          ptr(g_loss, torch.float32), pg, ldg, _stream()), 'psvae_link_ce_bwd_input')
+
+
+def token_ce_fwd(logits, gold, ignore_index, dlogits, loss, counts):
+    """logits [R,V] (rows of any stride), gold int32 [R] -> dlogits [R,V], loss f32[2], counts i32[2]."""
+    L = lib()
+    R, V = logits.shape
+    pl, ld = _rows(logits) if R else (None, V)
+    nbytes = L.psvae_token_ce_workspace_bytes(R)
+    ws = workspace(nbytes, loss.device)
+    _check(L.psvae_token_ce_fwd(R, V, pl, ld, ptr(gold, torch.int32), int(ignore_index), ptr(dlogits, torch.float32),
+                                ptr(loss, torch.float32), ptr(counts, torch.int32), ptr(ws), nbytes, _stream()),
+           'psvae_token_ce_fwd')
 
 
 def link_infer(logits, add_edge_th, none_bond, conf, etype, keep):

@@ -41,7 +41,11 @@ class Encoder(nn.Module):
         multiplies the one-hot edge_attr [E,C] by W^T, src/modules/encoder.py:55)."""
         return self.edge_trans.weight.t() + self.edge_trans.bias
 
-    def embed_node(self, x, edge_index, edge_attr=None):
+    def embed_node(self, x, edge_index, edge_attr=None, want_all=True):
+        """(last iterate [V,H], concatenation of the t iterates [V, t*H]) as src/modules/encoder.py:53-61.
+        want_all=False (a caller that only uses the last iterate, as the decoder does,
+        src/modules/vae_piece_decoder.py:93-96) returns (last, None) and spares the backward pass a
+        [V, t*H] gradient that is zero outside its last slot."""
         if isinstance(edge_index, ops.Csr):
             csr = edge_index
         else:
@@ -56,22 +60,22 @@ class Encoder(nn.Module):
             if fused and hidden % 4 == 0:
                 # node_trans straight from the embedding ids: no [V, dim_in] rows, no product over them
                 x0 = ops.embed_trans(x, self.node_trans.weight, self.node_trans.bias)
-                all_x = ops.gine_encoder(x0, None, None, self.edge_table(), mlp[0].weight, mlp[0].bias,
-                                         mlp[2].weight, mlp[2].bias, csr, self.t)
-                return all_x[:, (self.t - 1) * hidden:], all_x
+                out = ops.gine_encoder(x0, None, None, self.edge_table(), mlp[0].weight, mlp[0].bias,
+                                       mlp[2].weight, mlp[2].bias, csr, self.t, not want_all)
+                return (out[:, (self.t - 1) * hidden:], out) if want_all else (out, None)
             x = x.rows()
         if fused:
             # the reference's configuration (MLP(H, H, H, ReLU, 2), encoder.py:48): one fused node
-            all_x = ops.gine_encoder(x.float(), self.node_trans.weight, self.node_trans.bias, self.edge_table(),
-                                     mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias, csr, self.t)
-            return all_x[:, (self.t - 1) * hidden:], all_x
+            out = ops.gine_encoder(x.float(), self.node_trans.weight, self.node_trans.bias, self.edge_table(),
+                                   mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias, csr, self.t, not want_all)
+            return (out[:, (self.t - 1) * hidden:], out) if want_all else (out, None)
         x = run_linear(self.node_trans, x.float())
         table = self.edge_table()
         all_x = []
         for _ in range(self.t):
             x = self.conv(x, csr, table)
             all_x.append(x)
-        return x, torch.cat(all_x, dim=-1)
+        return x, (torch.cat(all_x, dim=-1) if want_all else None)
 
     def embed_graph(self, all_x, graph_ids, node_mask=None):
         if isinstance(graph_ids, ops.Segments):

@@ -69,21 +69,33 @@ class VAEPieceDecoder(nn.Module):
                              self.piece_embedding.weight, self.pos_embedding.weight)
         return out.view(*shape, out.shape[-1])
 
-    def piece_logits(self, z_vecs, pieces, piece_table=None):
+    def piece_logits(self, z_vecs, pieces, piece_table=None, time_major=False):
         """:81-90 — teacher-forced GRU over the piece sequence, initial state from z.
         piece_table: self.piece_embedding.weight as the caller wants it seen by autograd (the
-        two-stream schedule hands it over from the main stream)."""
+        two-stream schedule hands it over from the main stream).  Returns [B, S-1, vocab]; with
+        time_major=True the same logits as the GRU path produces them, [S-1, B, vocab] (no
+        transposition: a loss that is a mean over tokens does not care about their order)."""
         rnn = self.rnn
         init_hidden = run_linear(self.latent_to_rnn_hidden, z_vecs)
         if rnn.num_layers == 1 and not rnn.bidirectional and rnn.bias:
-            # time-major ids -> [T,B,E] embeddings -> HIP GRU; logits returned batch-major
+            # time-major ids -> [T,B,E] embeddings -> HIP GRU
             ids = pieces[:, :-1].t().contiguous().to(torch.int32)
             table = self.piece_embedding.weight if piece_table is None else piece_table
             emb = ops.embedding(ids, table) if table.shape[1] % 4 == 0 else self.piece_embedding(ids.long())
             hs = ops.gru(emb, init_hidden, rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.bias_ih_l0, rnn.bias_hh_l0)
-            return run_linear(self.to_vocab, hs).transpose(0, 1)
+            out = run_linear(self.to_vocab, hs)
+            return out if time_major else out.transpose(0, 1)
         output, _ = rnn(self.piece_embedding(pieces)[:, :-1], init_hidden.unsqueeze(0))
-        return run_linear(self.to_vocab, output)
+        out = run_linear(self.to_vocab, output)
+        return out.transpose(0, 1) if time_major else out
+
+    def piece_loss_fused(self, z_vecs, pieces, piece_table=None):
+        """:81-90 + :113-114 (+ the counts behind :120-122): the piece language model's logits and
+        their cross-entropy against pieces[:, 1:] with <pad> ignored, in one kernel on the
+        time-major logits.  Returns (loss, counts int32 [non-pad tokens, correct argmax])."""
+        logits = self.piece_logits(z_vecs, pieces, piece_table, time_major=True)
+        gold = pieces[:, 1:].t().contiguous().to(torch.int32)
+        return ops.token_ce(logits, gold, self.piece_loss.ignore_index)
 
     def link_logits(self, node_embedding, z_vecs, pairs, golden=None):
         """:99-110 (+ :115 when `golden` is given).  node_embedding [V,H] in the node ids the
@@ -138,7 +150,7 @@ class VAEPieceDecoder(nn.Module):
             node_x = ids.for_side_stream()   # the embedding tables are shared with the main-stream encoder
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            node_embedding, _ = self.graph_embedding.embed_node(node_x, csr, None)
+            node_embedding, _ = self.graph_embedding.embed_node(node_x, csr, None, want_all=False)
         for t in (ids.tensors() if ids is not None else (node_x,)):
             t.record_stream(side)
         return node_embedding, side
@@ -149,13 +161,10 @@ class VAEPieceDecoder(nn.Module):
         in-piece edges, edge_select [B,N,N] bool, golden_edge [P] int64) or the compact
         containers (x [V,D], edge_index = ops.Csr, edge_select = ops.PairList)."""
         z_vecs, kl_loss = self.rsample(conds, eps)
-        gold_piece = pieces[:, 1:].flatten()
         side = node_embedding[1] if node_embedding is not None else None
 
         def piece_branch(piece_table=None):
-            output = self.piece_logits(z_vecs, pieces, piece_table)
-            pred_piece = output.reshape(-1, output.shape[-1])
-            return pred_piece, self.piece_loss(pred_piece, gold_piece)
+            return self.piece_loss_fused(z_vecs, pieces, piece_table)
 
         if side is not None:
             # The piece language model (many small, latency-bound launches) shares the chip with
@@ -169,27 +178,27 @@ class VAEPieceDecoder(nn.Module):
             piece_table = ops.stream_handoff(self.piece_embedding.weight)
             side.wait_stream(main)                  # z_vecs is complete
             with torch.cuda.stream(side):
-                pred_piece, piece_loss = piece_branch(piece_table)
-            for t in (z_vecs, pieces, gold_piece):
+                piece_loss, piece_counts = piece_branch(piece_table)
+            for t in (z_vecs, pieces):
                 t.record_stream(side)
         else:
             node_x = x if isinstance(x, ops.EmbeddedIds) else x.reshape(-1, x.shape[-1])
-            node_embedding, _ = self.graph_embedding.embed_node(node_x, edge_index, edge_attr)
+            node_embedding, _ = self.graph_embedding.embed_node(node_x, edge_index, edge_attr, want_all=False)
         pairs = edge_select if isinstance(edge_select, ops.PairList) else ops.PairList.from_edge_select(edge_select)
         golden = golden_edge if golden_edge.dtype == torch.int32 else golden_edge.to(torch.int32)
         pred_edge, edge_loss, n_ok = self.link_logits(node_embedding, z_vecs, pairs, golden)
 
         if side is not None:
             main.wait_stream(side)
-            pred_piece.record_stream(main)
+            piece_counts.record_stream(main)
             piece_loss.record_stream(main)
         else:
-            pred_piece, piece_loss = piece_branch()
+            piece_loss, piece_counts = piece_branch()
         rec_loss = piece_loss + edge_loss
         loss_tuple = (rec_loss, piece_loss, edge_loss, kl_loss)
         if return_accu:
-            not_pad = (gold_piece != self.tokenizer.pad_idx())
-            piece_accu = ((torch.argmax(pred_piece, dim=-1) == gold_piece) & not_pad).sum().item() / not_pad.sum().item()
+            n_tok, n_hit = piece_counts.tolist()     # non-pad tokens, those whose argmax is the gold piece
+            piece_accu = n_hit / n_tok
             edge_accu = n_ok.item() / len(golden)
             return z_vecs, (loss_tuple, (piece_accu, edge_accu))
         return z_vecs, loss_tuple
@@ -204,7 +213,7 @@ class VAEPieceDecoder(nn.Module):
         dev = self.W_mean.weight.device
         n = x.numel()
         node_x = self.embed_atom(x.to(dev), x_pieces.to(dev), x_pos.to(dev))
-        h, _ = self.graph_embedding.embed_node(node_x, edge_index.to(dev), edge_attr.to(dev))
+        h, _ = self.graph_embedding.embed_node(node_x, edge_index.to(dev), edge_attr.to(dev), want_all=False)
         frag = torch.full((n,), -1, dtype=torch.int64)
         for gi, g in enumerate(groups):
             frag[torch.as_tensor(g, dtype=torch.int64)] = gi
@@ -339,7 +348,7 @@ class VAEPieceDecoder(nn.Module):
                        order_ptr=torch.zeros(B + 1, dtype=torch.int64, device=dev))
             return out
         node_x = self.embed_atom(x.to(dev), x_pieces.to(dev), x_pos.to(dev))
-        h, _ = self.graph_embedding.embed_node(node_x, csr_in, None)
+        h, _ = self.graph_embedding.embed_node(node_x, csr_in, None, want_all=False)
         logits, _, _ = self.link_logits(h, z.to(dev).view(B, -1), pairs)
         conf = torch.empty(P, dtype=torch.float32, device=dev)
         etype = torch.empty(P, dtype=torch.int32, device=dev)

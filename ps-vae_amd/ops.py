@@ -199,8 +199,11 @@ class _GineEncoder(Function):
     taken from the same pass."""
 
     @staticmethod
-    def forward(ctx, x_in, w0, b0, table, w1, b1, w2, b2, csr, t):
-        """w0 None: x_in [V,H] already is node_trans' output (see embed_trans)."""
+    def forward(ctx, x_in, w0, b0, table, w1, b1, w2, b2, csr, t, only_last=False):
+        """w0 None: x_in [V,H] already is node_trans' output (see embed_trans).
+        only_last: return the last iterate alone (its slot of the internal buffer) - the caller that
+        uses nothing else then gets a [V,H] gradient instead of a [V, t*H] one that is zero in t-1
+        of its t slots."""
         x_in = _rows2d(x_in)
         V, Din = x_in.shape
         H = w1.shape[1]
@@ -225,9 +228,9 @@ class _GineEncoder(Function):
             slot = all_x[:, i * H:(i + 1) * H]
             hip.gemm(V, H, H, h[i], H, 1, w2, 1, H, slot, t * H, bias=b2)
             prev = slot
-        ctx.csr, ctx.t = csr, t
+        ctx.csr, ctx.t, ctx.only_last = csr, t, only_last
         ctx.save_for_backward(x_in, w0, table, w1, w2, x0, all_x, a, h)
-        return all_x
+        return all_x[:, (t - 1) * H:] if only_last else all_x
 
     @staticmethod
     def backward(ctx, g_all):
@@ -235,21 +238,25 @@ class _GineEncoder(Function):
         csr, t = ctx.csr, ctx.t
         V, H = x0.shape
         dev = x0.device
-        g_all = g_all if (g_all.dtype == torch.float32 and g_all.is_contiguous()) else g_all.float().contiguous()
+        only_last = ctx.only_last      # then g_all is the gradient of the last iterate alone, [V,H]
+        if g_all.dtype != torch.float32:
+            g_all = g_all.float()
+        if not only_last and not g_all.is_contiguous():
+            g_all = g_all.contiguous()
         f32 = dict(dtype=torch.float32, device=dev)
         gx = torch.empty(t, V, H, **f32)      # dL/d x_i (output of layer i), stacked for the dW2 product
         gh = torch.empty(t, V, H, **f32)      # dL/d (pre-activation of h_i): gated as it is produced
         ga = torch.empty(V, H, **f32)
         g_x0 = torch.empty(V, H, **f32)
         g_table = torch.empty_like(table)
-        gx[t - 1].copy_(g_all[:, (t - 1) * H:])
+        gx[t - 1].copy_(g_all if only_last else g_all[:, (t - 1) * H:])
         for i in range(t - 1, -1, -1):
             hip.gemm(V, H, H, gx[i], H, 1, w2, H, 1, gh[i], H, cmask=h[i])      # through the last Linear + ReLU
             hip.gemm(V, H, H, gh[i], H, 1, w1, H, 1, ga, H)                     # through the first Linear
             first = i == t - 1
             if i > 0:
                 hip.gine_aggregate_bwd(all_x[:, (i - 1) * H:i * H], table, ga, csr.t_row_ptr, csr.t_col, csr.t_cls,
-                                       gx[i - 1], g_table, add=g_all[:, (i - 1) * H:i * H],
+                                       gx[i - 1], g_table, add=None if only_last else g_all[:, (i - 1) * H:i * H],
                                        accumulate_table=not first)
             else:
                 hip.gine_aggregate_bwd(x0, table, ga, csr.t_row_ptr, csr.t_col, csr.t_cls, g_x0, g_table,
@@ -262,7 +269,7 @@ class _GineEncoder(Function):
         hip.gemm(H, H, TV, gx2, 1, H, h2, H, 1, gw2, H, split_k=0, rowsum=gb2)
         hip.gemm(H, H, TV, gh2, 1, H, a2, H, 1, gw1, H, split_k=0, rowsum=gb1)
         if w0 is None:
-            return g_x0, None, None, g_table, gw1, gb1, gw2, gb2, None, None
+            return g_x0, None, None, g_table, gw1, gb1, gw2, gb2, None, None, None
         Din = x_in.shape[1]
         gw0, gb0 = torch.empty_like(w0), torch.empty(H, **f32)
         hip.gemm(H, Din, V, g_x0, 1, H, x_in, _ld(x_in), 1, gw0, Din, split_k=0, rowsum=gb0)
@@ -270,12 +277,12 @@ class _GineEncoder(Function):
         if need[0]:
             g_in = torch.empty(V, Din, **f32)
             hip.gemm(V, Din, H, g_x0, H, 1, w0, Din, 1, g_in, Din)
-        return g_in, gw0, gb0, g_table, gw1, gb1, gw2, gb2, None, None
+        return g_in, gw0, gb0, g_table, gw1, gb1, gw2, gb2, None, None, None
 
 
-def gine_encoder(x_in, w0, b0, table, w1, b1, w2, b2, csr, t):
-    """[V, t*H] concatenation of the t GINE iterates of node_trans(x_in)."""
-    return _GineEncoder.apply(x_in, w0, b0, table, w1, b1, w2, b2, csr, t)
+def gine_encoder(x_in, w0, b0, table, w1, b1, w2, b2, csr, t, only_last=False):
+    """[V, t*H] concatenation of the t GINE iterates of node_trans(x_in); only_last: the last one, [V,H]."""
+    return _GineEncoder.apply(x_in, w0, b0, table, w1, b1, w2, b2, csr, t, only_last)
 
 
 # ------------------------------------------------------------------------ embed_atom
@@ -683,3 +690,34 @@ def link_ce(hid, weight, bias, golden):
     """Last Linear of the link predictor + mean 4-class cross-entropy.
     Returns (loss, logits [P,C], n_correct)."""
     return _LinkCe.apply(hid, weight, bias, golden)
+
+
+# ------------------------------------------------------------------------ token loss with an ignored label
+class _TokenCe(Function):
+    @staticmethod
+    def forward(ctx, logits, gold, ignore_index):
+        x = _rows2d(logits)
+        R, V = x.shape
+        dev = x.device
+        dlogits = torch.empty(R, V, dtype=torch.float32, device=dev)
+        loss = torch.empty(2, dtype=torch.float32, device=dev)
+        counts = torch.empty(2, dtype=torch.int32, device=dev)
+        hip.token_ce_fwd(x, gold, ignore_index, dlogits, loss, counts)
+        ctx.save_for_backward(dlogits, loss)
+        ctx.shape = logits.shape
+        ctx.mark_non_differentiable(counts)
+        return loss[0], counts
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_counts):
+        dlogits, loss = ctx.saved_tensors
+        # the saved rows are softmax - onehot: times g_loss / #tokens they are the gradient
+        return (dlogits * (g_loss.float() * loss[1])).view(ctx.shape), None, None
+
+
+def token_ce(logits, gold, ignore_index):
+    """Mean cross-entropy over the rows whose label is not `ignore_index`
+    (nn.CrossEntropyLoss(ignore_index=...)).  logits [..., V] f32, gold int32 [...] (same leading
+    shape, flattened).  Returns (loss, counts) with counts = int32 [#rows counted, #rows whose
+    argmax is the label]."""
+    return _TokenCe.apply(logits.reshape(-1, logits.shape[-1]), gold.reshape(-1), ignore_index)

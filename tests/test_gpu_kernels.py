@@ -777,3 +777,42 @@ def test_assemble_links_rejects_bad_ids(tokenizer):
                        torch.tensor([0, 1], dtype=i32, device=d), z(1), z(1) + 1, z(1) + 1,
                        torch.full((10,), 4, dtype=i32, device=d), 9, acc, blk, keep, status)
     assert status.item() == 2 and acc.item() == 0 and keep.cpu().tolist() == [0, 0]
+
+
+# ------------------------------------------------------------------ piece loss (CE with an ignored label)
+@pytest.mark.parametrize('R,V,ld', [(45056, 302, 302), (1000, 302, 320), (7, 1, 1), (130, 64, 64), (129, 65, 80),
+                                    (50, 1000, 1000), (0, 302, 302)])
+def test_token_ce_against_torch(R, V, ld):
+    """psvae_token_ce_fwd + its autograd wrapper against nn.CrossEntropyLoss(ignore_index) in
+    float64: loss, gradient of the logits, token count and argmax hits."""
+    from ps_vae_amd import ops as hip_ops
+    d = dev()
+    g = torch.Generator().manual_seed(R + V)
+    buf = torch.randn(R, ld, generator=g) * 3
+    gold = torch.randint(0, V, (R,), generator=g)
+    ignore = V - 1 if V > 1 else 5
+    if R:
+        gold[torch.rand(R, generator=g) < 0.3] = ignore
+    logits = buf[:, :V].to(d).requires_grad_(True) if ld == V else buf.to(d)[:, :V].requires_grad_(True)
+    loss, counts = hip_ops.token_ce(logits, gold.to(d).to(torch.int32), ignore)
+    ref_x = buf[:, :V].double().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(ref_x, gold, ignore_index=ignore) if R else torch.tensor(float('nan'))
+    live = gold != ignore
+    if int(live.sum()) == 0:
+        assert torch.isnan(loss).item()
+        return
+    assert abs(loss.item() - ref.item()) <= 1e-5 * abs(ref.item())
+    (loss * 0.37).backward()
+    (ref * 0.37).backward()
+    close(logits.grad, ref_x.grad, what='dlogits')
+    hits = int(((ref_x.argmax(-1) == gold) & live).sum())
+    assert counts.tolist() == [int(live.sum()), hits]
+
+
+def test_token_ce_all_rows_ignored_is_nan():
+    from ps_vae_amd import ops as hip_ops
+    d = dev()
+    logits = torch.randn(9, 12, device=d)
+    gold = torch.full((9,), 3, dtype=torch.int32, device=d)
+    loss, counts = hip_ops.token_ce(logits, gold, 3)
+    assert torch.isnan(loss).item() and counts.tolist() == [0, 0]
