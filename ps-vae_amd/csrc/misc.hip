@@ -116,7 +116,15 @@ __global__ void segment_sum_fwd_kernel(int cols, const float4 *__restrict__ x, i
     const int r0 = seg_begin[b], r1 = seg_end[b];
     for (int c = threadIdx.x; c < cols; c += blockDim.x) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int r = r0; r < r1; ++r) acc = add4(acc, x[(long long)r * ldx4 + c]);
+        // four rows requested at once (indices clamped, contributions predicated, summed in row order)
+        for (int r = r0; r < r1; r += 4) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = x[(long long)min(r + u, r1 - 1) * ldx4 + c];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (r + u < r1) acc = add4(acc, v[u]);
+        }
         out[(long long)b * ldo4 + c] = acc;
     }
 }
@@ -140,7 +148,7 @@ __global__ __launch_bounds__(1024) void rsample_kl_fwd_kernel(int B, int L, cons
     __shared__ float sh[1024];
     const int total = B * L;
     float s = 0.f;
-    constexpr int U = 8;   // loads in flight per thread: the single workgroup is latency-bound
+    constexpr int U = 24;  // loads in flight per thread: the single workgroup is latency-bound
     for (int i0 = threadIdx.x; i0 < total; i0 += 1024 * U) {
         float m[U], pre[U], e[U];
 #pragma unroll
