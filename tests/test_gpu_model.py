@@ -374,6 +374,81 @@ def test_loss_curve_follows_the_oracle_over_30_steps(tokenizer):
           f'(fp32 CPU oracle there: {worst[3]:.2e}); loss {curve[0]:.4f} -> {curve[-1]:.4f}')
 
 
+@pytest.mark.parametrize('shape', ['qm9', 'zinc'])
+def test_batch_32_train_step_against_oracle(tokenizer, shape):
+    """One full training step at batch 32, default widths, on QM9-shaped molecules (at most 9
+    atoms: the reference's own CPU configuration) and ZINC-shaped ones: GPU collation bit-exact
+    against the oracle's, every loss, every parameter gradient, the clipped gradient norm and
+    every parameter after the Adam step against the oracle in float64 (a gradient may instead
+    be as close to float64 as twice the fp32 CPU oracle's own distance: summation order)."""
+    import copy
+    from ps_vae_amd.data.collate import collate_packed
+    from ps_vae_amd.data.packed import PackedMolecules
+    from ps_vae_amd.data.synthetic import synthetic_step1
+    B = 32
+    step1 = synthetic_step1(B, seed=55, shape=shape)
+    uniforms = np.random.default_rng(8).random(1500 * B)
+    want_batch, used = collate_ref.collate(step1, uniforms, piece_pad=tokenizer.pad_idx())
+    cfg = model_ref.default_config(tokenizer)
+    torch.manual_seed(12)
+    ref = model_ref.PSVAEModel(cfg, tokenizer)
+    ref64 = copy.deepcopy(ref).double()
+    model, _ = hip_model(tokenizer, state=ref.state_dict())
+    (opt,), _ = model.configure_optimizers()
+    opt.max_norm = 10.0
+    eps = torch.randn(B, 56, generator=torch.Generator().manual_seed(6))
+    tb = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in want_batch.items()}
+    tb64 = {k: (v.double() if v.dtype == torch.float32 else v) for k, v in tb.items()}
+
+    packed = PackedMolecules.from_step1(step1)
+    batch = collate_packed(packed.to_device(dev()), np.arange(B), uniforms=torch.from_numpy(uniforms).to(dev()),
+                           atom_pad=tokenizer.atom_pad_idx(), piece_pad=tokenizer.pad_idx())
+    assert batch.num_uniforms == used
+    for k, v in want_batch.items():       # the reference layout, bit for bit
+        got = batch[k].cpu().numpy()
+        assert got.shape == v.shape and np.array_equal(got, v), k
+
+    def run(m, b, e):
+        pl, (rec, piece, edge, kl) = m(b, e)
+        loss = m.weighted_loss(pl, rec, kl)
+        loss.backward()
+        return dict(loss=loss.item(), pred=pl.item(), rec=rec.item(), piece=piece.item(), edge=edge.item(), kl=kl.item())
+    l32, l64 = run(ref, tb, eps), run(ref64, tb64, eps.double())
+    opt.zero_grad()
+    gpl, (grec, gpiece, gedge, gkl) = model(batch, eps=eps.to(dev()))
+    gloss = model.weighted_loss(gpl, grec, gkl)
+    gloss.backward()
+    got = dict(loss=gloss.item(), pred=gpl.item(), rec=grec.item(), piece=gpiece.item(), edge=gedge.item(), kl=gkl.item())
+    for k, v in l64.items():
+        assert abs(got[k] - v) <= 1e-5 * abs(v), (k, got[k], v, l32[k])
+    p32, p64 = dict(ref.named_parameters()), dict(ref64.named_parameters())
+    for k, p in model.named_parameters():
+        if p64[k].grad is None:
+            assert p.grad is None or not bool(p.grad.any()), k
+            continue
+        g64 = p64[k].grad
+        scale = g64.abs().max().item()
+        err_gpu = (p.grad.cpu().double() - g64).abs().max().item()
+        err_cpu = (p32[k].grad.double() - g64).abs().max().item()
+        assert err_gpu <= max(1e-5 * scale, 2.0 * err_cpu), f'grad {k}: {err_gpu / scale:.2e} (fp32 oracle {err_cpu / scale:.2e})'
+    g64 = {k: q.grad.clone() for k, q in p64.items() if q.grad is not None}
+    norm64 = torch.nn.utils.clip_grad_norm_(ref64.parameters(), 10.0)
+    torch.optim.Adam(ref64.parameters(), lr=cfg['lr']).step()
+    opt.step()
+    assert abs(float(opt.grad_norm) - norm64.item()) <= 1e-5 * norm64.item()
+    for k, p in model.named_parameters():
+        if k not in g64:
+            continue
+        # Adam's first step is lr * g / (|g| + 1e-8): where |g| is not far above 1e-8 the step depends on
+        # the gradient's last bits, so the values are compared where the gradient is clear of that
+        clear = g64[k].abs() > 1e-5
+        if not bool(clear.any()):
+            continue
+        want, got_p = p64[k].detach()[clear], p.detach().cpu().double()[clear]
+        err = (got_p - want).abs().max().item()
+        assert err <= 2e-5 * max(want.abs().max().item(), 1e-3), f'{k}: {err:.3e} vs values up to {want.abs().max().item():.3e}'
+
+
 def test_infer_links_against_reference_golden(tokenizer):
     gold = load_npz('infer_links.npz')
     state = {k: torch.from_numpy(v) for k, v in sub(gold, 'state').items()}
