@@ -104,7 +104,9 @@ int psvae_exclusive_scan_i32(int n, const int32_t *in, int32_t *out, void *strea
 /* ------------------------------------------------------------------------------------
  * embed_atom: out[v] = [ E_atom[x[v]] | E_piece[xp[v]] | E_pos[xq[v]] ]
  * (src/modules/vae_piece_decoder.py:65-69).  Backward adds g_out rows into the three
- * table gradients (float atomics; caller zero-fills them).
+ * table gradients (float atomics; caller zero-fills them).  An id outside its table is clamped
+ * into it, by the same rule in every entry point that takes ids (forward, backward, indicator,
+ * psvae_embed_trans_fwd, psvae_embedding_fwd): nothing is read or added outside a table.
  * ---------------------------------------------------------------------------------- */
 int psvae_embed_atom_fwd(int V, const int32_t *x, const int32_t *xp, const int32_t *xq,
                          const float *e_atom, int n_atom, int d_atom,

@@ -28,10 +28,15 @@ int grid_for(long long items, int threads, int cap = 4096) {
 }
 
 // ---------------------------------------------------------------- embed_atom
+// Every kernel that looks an id up clamps it into its table first (the same rule in the forward,
+// the backward, the indicator and embed_trans), so a bad id can neither read nor add outside a
+// table and all of them agree on which row it means.
+__device__ __forceinline__ int clamp_id(int id, int n) { return min(max(id, 0), n - 1); }
+
 __global__ void embed_atom_fwd_kernel(int V, const int32_t *__restrict__ x, const int32_t *__restrict__ xp,
-                                      const int32_t *__restrict__ xq, const float *__restrict__ ea, int da,
-                                      const float *__restrict__ ep, int dp, const float *__restrict__ eq, int dq,
-                                      float *__restrict__ out) {
+                                      const int32_t *__restrict__ xq, const float *__restrict__ ea, int na, int da,
+                                      const float *__restrict__ ep, int np, int dp, const float *__restrict__ eq,
+                                      int nq, int dq, float *__restrict__ out) {
     const int D = da + dp + dq;
     const long long total = (long long)V * D;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -39,18 +44,19 @@ __global__ void embed_atom_fwd_kernel(int V, const int32_t *__restrict__ x, cons
         const int v = (int)(i / D), d = (int)(i - (long long)v * D);
         float val;
         if (d < da)
-            val = ea[x[v] * da + d];
+            val = ea[clamp_id(x[v], na) * da + d];
         else if (d < da + dp)
-            val = ep[xp[v] * dp + (d - da)];
+            val = ep[clamp_id(xp[v], np) * dp + (d - da)];
         else
-            val = eq[xq[v] * dq + (d - da - dp)];
+            val = eq[clamp_id(xq[v], nq) * dq + (d - da - dp)];
         out[i] = val;
     }
 }
 
 __global__ void embed_atom_bwd_kernel(int V, const int32_t *__restrict__ x, const int32_t *__restrict__ xp,
-                                      const int32_t *__restrict__ xq, const float *__restrict__ g, int da, int dp,
-                                      int dq, float *__restrict__ ga, float *__restrict__ gp, float *__restrict__ gq) {
+                                      const int32_t *__restrict__ xq, const float *__restrict__ g, int na, int da,
+                                      int np, int dp, int nq, int dq, float *__restrict__ ga,
+                                      float *__restrict__ gp, float *__restrict__ gq) {
     const int D = da + dp + dq;
     const long long total = (long long)V * D;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -58,22 +64,22 @@ __global__ void embed_atom_bwd_kernel(int V, const int32_t *__restrict__ x, cons
         const int v = (int)(i / D), d = (int)(i - (long long)v * D);
         const float val = g[i];
         if (d < da)
-            atomicAdd(&ga[x[v] * da + d], val);
+            atomicAdd(&ga[clamp_id(x[v], na) * da + d], val);
         else if (d < da + dp)
-            atomicAdd(&gp[xp[v] * dp + (d - da)], val);
+            atomicAdd(&gp[clamp_id(xp[v], np) * dp + (d - da)], val);
         else
-            atomicAdd(&gq[xq[v] * dq + (d - da - dp)], val);
+            atomicAdd(&gq[clamp_id(xq[v], nq) * dq + (d - da - dp)], val);
     }
 }
 
 __global__ void embed_atom_onehot_kernel(int V, const int32_t *__restrict__ x, const int32_t *__restrict__ xp,
-                                         const int32_t *__restrict__ xq, int na, int np, float4 *__restrict__ out,
-                                         int ld4) {
+                                         const int32_t *__restrict__ xq, int na, int np, int nq,
+                                         float4 *__restrict__ out, int ld4) {
     const long long total = (long long)V * ld4;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
         const int v = (int)(i / ld4), j = (int)(i - (long long)v * ld4) * 4;
-        const int a = x[v], b = na + xp[v], c = na + np + xq[v];
+        const int a = clamp_id(x[v], na), b = na + clamp_id(xp[v], np), c = na + np + clamp_id(xq[v], nq);
         float4 o;
         o.x = (j == a || j == b || j == c) ? 1.f : 0.f;
         o.y = (j + 1 == a || j + 1 == b || j + 1 == c) ? 1.f : 0.f;
@@ -584,12 +590,12 @@ extern "C" int psvae_embed_atom_fwd(int V, const int32_t *x, const int32_t *xp, 
                                     const float *e_atom, int n_atom, int d_atom, const float *e_piece, int n_piece,
                                     int d_piece, const float *e_pos, int n_pos, int d_pos, float *out, void *stream) {
     PSVAE_REQUIRE(V >= 0 && d_atom >= 0 && d_piece >= 0 && d_pos >= 0, PSVAE_EINVAL, "psvae_embed_atom_fwd: bad sizes");
-    (void)n_atom, (void)n_piece, (void)n_pos;
+    PSVAE_REQUIRE(V == 0 || (n_atom > 0 && n_piece > 0 && n_pos > 0), PSVAE_EINVAL, "psvae_embed_atom_fwd: empty table");
     const long long total = (long long)V * (d_atom + d_piece + d_pos);
     if (total == 0) return PSVAE_OK;
     PSVAE_REQUIRE(x && xp && xq && e_atom && e_piece && e_pos && out, PSVAE_EINVAL, "psvae_embed_atom_fwd: null pointer");
     hipLaunchKernelGGL(embed_atom_fwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, V, x, xp,
-                       xq, e_atom, d_atom, e_piece, d_piece, e_pos, d_pos, out);
+                       xq, e_atom, n_atom, d_atom, e_piece, n_piece, d_piece, e_pos, n_pos, d_pos, out);
     PSVAE_CHECK_LAUNCH("psvae_embed_atom_fwd");
     return PSVAE_OK;
 }
@@ -598,20 +604,20 @@ extern "C" int psvae_embed_atom_bwd(int V, const int32_t *x, const int32_t *xp, 
                                     int n_atom, int d_atom, int n_piece, int d_piece, int n_pos, int d_pos,
                                     float *g_atom, float *g_piece, float *g_pos, void *stream) {
     PSVAE_REQUIRE(V >= 0 && d_atom >= 0 && d_piece >= 0 && d_pos >= 0, PSVAE_EINVAL, "psvae_embed_atom_bwd: bad sizes");
-    (void)n_atom, (void)n_piece, (void)n_pos;
+    PSVAE_REQUIRE(V == 0 || (n_atom > 0 && n_piece > 0 && n_pos > 0), PSVAE_EINVAL, "psvae_embed_atom_bwd: empty table");
     const long long total = (long long)V * (d_atom + d_piece + d_pos);
     if (total == 0) return PSVAE_OK;
     PSVAE_REQUIRE(x && xp && xq && g_out && g_atom && g_piece && g_pos, PSVAE_EINVAL, "psvae_embed_atom_bwd: null pointer");
     hipLaunchKernelGGL(embed_atom_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, V, x, xp,
-                       xq, g_out, d_atom, d_piece, d_pos, g_atom, g_piece, g_pos);
+                       xq, g_out, n_atom, d_atom, n_piece, d_piece, n_pos, d_pos, g_atom, g_piece, g_pos);
     PSVAE_CHECK_LAUNCH("psvae_embed_atom_bwd");
     return PSVAE_OK;
 }
 
 extern "C" int psvae_embed_atom_onehot(int V, const int32_t *x, const int32_t *xp, const int32_t *xq, int n_atom,
                                        int n_piece, int n_pos, float *out, int ld, void *stream) {
-    PSVAE_REQUIRE(V >= 0 && n_atom >= 0 && n_piece >= 0 && n_pos >= 0, PSVAE_EINVAL,
-                  "psvae_embed_atom_onehot: bad sizes");
+    PSVAE_REQUIRE(V >= 0 && n_atom >= 0 && n_piece >= 0 && n_pos >= 0 && (V == 0 || (n_atom > 0 && n_piece > 0 && n_pos > 0)),
+                  PSVAE_EINVAL, "psvae_embed_atom_onehot: bad sizes");
     PSVAE_REQUIRE(ld % 4 == 0 && ld >= n_atom + n_piece + n_pos && ld > 0, PSVAE_EINVAL,
                   "psvae_embed_atom_onehot: ld=%d must be a multiple of 4 covering %d ids", ld,
                   n_atom + n_piece + n_pos);
@@ -619,7 +625,7 @@ extern "C" int psvae_embed_atom_onehot(int V, const int32_t *x, const int32_t *x
     PSVAE_REQUIRE(x && xp && xq && out && psvae_aligned16(out), PSVAE_EINVAL,
                   "psvae_embed_atom_onehot: null or misaligned pointer");
     hipLaunchKernelGGL(embed_atom_onehot_kernel, dim3(grid_for((long long)V * (ld / 4), 256, 16384)), dim3(256), 0,
-                       (hipStream_t)stream, V, x, xp, xq, n_atom, n_piece, (float4 *)out, ld / 4);
+                       (hipStream_t)stream, V, x, xp, xq, n_atom, n_piece, n_pos, (float4 *)out, ld / 4);
     PSVAE_CHECK_LAUNCH("psvae_embed_atom_onehot");
     return PSVAE_OK;
 }

@@ -44,7 +44,19 @@ class BPEMolDataset(torch.utils.data.Dataset):
                                             f'{fname} is process_step1 (RDKit), outside this package')
         if data is not None:
             self.packed = data if isinstance(data, PackedMolecules) else PackedMolecules.from_step1(data)
+        self._check_ids()
         self.dpacked = self.packed.to_device(self.device)
+
+    def _check_ids(self):
+        """Every atom type, piece id and bond class must index the tokenizer's tables: the
+        reference's nn.Embedding raises on such an id, the kernels here clamp it, so it is refused
+        once, on the host, when the dataset is built."""
+        p, tok = self.packed, self.tokenizer
+        checks = (('atom type', p.atom_type, tok.num_atom_type()), ('piece id', p.piece_id, tok.num_piece_type()),
+                  ('bond class', p.bond_cls, tok.chem_vocab.num_bond_type()))
+        for what, arr, n in checks:
+            if arr.size and (int(arr.min()) < 0 or int(arr.max()) >= n):
+                raise ValueError(f'{what} outside [0, {n}): {int(arr.min())} .. {int(arr.max())}')
 
     @staticmethod
     def process_step2(data, tokenizer):
