@@ -284,6 +284,17 @@ int psvae_pair_gather_bwd(int B, int H, int L, const float *g_feats,
 int psvae_pair_combine_fwd(int P, int F, const float *a, int lda, const float *b, int ldb,
                            const float *c, int ldc, const int32_t *src, const int32_t *dst,
                            const int32_t *graph, int act, float *out, int ldo, void *stream);
+/* Its backward for a = ab[:, :F], b = ab[:, F:] (one [V, 2F] matrix, as (h [Wa;Wb]^T) produces it): with
+ * m[p] = g_out[p] gated by out[p] > 0 when act is ReLU (`out` = the forward's result),
+ * g_ab[v][:F] = sum of m[p] over pairs with src[p] == v, g_ab[v][F:] = the same over dst[p] == v,
+ * g_c[b] = sum of m[p] over the pairs of graph b — every sum in pair order, no atomics (the training
+ * form of the link predictor's first layer, src/modules/vae_piece_decoder.py:99-110: the [P, 2H+L]
+ * feature rows and their gradient are never formed).  Pairs of graph b are pair_ptr[b] ..
+ * pair_ptr[b+1]-1 and refer to nodes node_begin[b] .. node_end[b]-1, whose g_ab rows are all written. */
+int psvae_pair_combine_bwd(int B, int F, const float *g_out, int ldg, const float *out, int ldo, int act,
+                           const int32_t *src, const int32_t *dst, const int32_t *pair_ptr,
+                           const int32_t *node_begin, const int32_t *node_end,
+                           float *g_ab, int ldab, float *g_c, int ldc, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Two Linear layers with no activation between them as one affine map — the link

@@ -324,6 +324,66 @@ __global__ void pair_gather_bwd_kernel(int h4, int l4, int slots, const float4 *
     if (zthread) g_z[(long long)b * ldgz4 + threadIdx.x] = zacc;
 }
 
+// Backward of pair_combine_fwd with a = ab[:, :F], b = ab[:, F:] (one [V, 2F] matrix): the gradient
+// of a pair's row, gated by the ReLU derivative (out > 0) when act is ReLU, is added to the a block of
+// its source node, the b block of its destination node and the row of its graph.  One workgroup per
+// graph, as pair_gather_bwd: thread (slot, c) owns column c of nodes slot, slot+slots, ... and walks
+// the staged pairs in order, so every sum runs in pair order.
+__global__ void pair_combine_bwd_kernel(int f4, int slots, int relu, const float4 *__restrict__ g_out, int ldg4,
+                                        const float4 *__restrict__ out, int ldo4, const int32_t *__restrict__ src,
+                                        const int32_t *__restrict__ dst, const int32_t *__restrict__ pair_ptr,
+                                        const int32_t *__restrict__ node_begin, const int32_t *__restrict__ node_end,
+                                        float4 *__restrict__ g_ab, int ldab4, float4 *__restrict__ g_c, int ldc4) {
+    __shared__ int s_src[PAIR_CHUNK], s_dst[PAIR_CHUNK];
+    const int b = blockIdx.x;
+    const int p0 = pair_ptr[b], p1 = pair_ptr[b + 1];
+    const int n0 = node_begin[b], n1 = node_end[b];
+    const int c = threadIdx.x % f4, slot = threadIdx.x / f4;
+    const bool active = slot < slots;
+    auto row = [&](int p, int col) {
+        float4 g = g_out[(long long)p * ldg4 + col];
+        if (relu) {
+            const float4 o = out[(long long)p * ldo4 + col];
+            g.x = o.x > 0.f ? g.x : 0.f, g.y = o.y > 0.f ? g.y : 0.f, g.z = o.z > 0.f ? g.z : 0.f, g.w = o.w > 0.f ? g.w : 0.f;
+        }
+        return g;
+    };
+    float4 cacc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool cthread = (int)threadIdx.x < f4;
+    bool first = true;
+    int pc = p0;
+    do {   // runs once even without pairs so that the outputs are written
+        const int cnt = min(PAIR_CHUNK, p1 - pc);
+        __syncthreads();
+        for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+            s_src[i] = src[pc + i] - n0;
+            s_dst[i] = dst[pc + i] - n0;
+        }
+        __syncthreads();
+        if (active) {
+            for (int j = slot; j < n1 - n0; j += slots) {
+                float4 *ga = g_ab + (long long)(n0 + j) * ldab4 + c, *gb = ga + f4;
+                float4 acc_a = first ? make_float4(0.f, 0.f, 0.f, 0.f) : *ga;
+                float4 acc_b = first ? make_float4(0.f, 0.f, 0.f, 0.f) : *gb;
+                for (int i = 0; i < cnt; ++i) {
+                    const bool is_src = s_src[i] == j, is_dst = s_dst[i] == j;
+                    if (is_src || is_dst) {
+                        const float4 m = row(pc + i, c);
+                        if (is_src) acc_a = add4(acc_a, m);
+                        if (is_dst) acc_b = add4(acc_b, m);
+                    }
+                }
+                *ga = acc_a, *gb = acc_b;
+            }
+        }
+        if (cthread)
+            for (int i = 0; i < cnt; ++i) cacc = add4(cacc, row(pc + i, threadIdx.x));
+        first = false;
+        pc += cnt;
+    } while (pc < p1);
+    if (cthread) g_c[(long long)b * ldc4 + threadIdx.x] = cacc;
+}
+
 // ---------------------------------------------------------------- two stacked Linears as one
 // W_eff = W_last W_out, b_eff = W_last b_out + b_last (no activation between the layers).
 // Thread (kq, jg) of a workgroup sums j = jg, jg+32, ... for column k = 32*blockIdx.x + kq and
@@ -762,6 +822,32 @@ extern "C" int psvae_pair_combine_fwd(int P, int F, const float *a, int lda, con
     hipLaunchKernelGGL(pair_combine_fwd_kernel, dim3(grid_for((long long)P * (F / 4), 256, 16384)), dim3(256), 0,
                        (hipStream_t)stream, P, F / 4, (const float4 *)a, lda / 4, (const float4 *)b, ldb / 4,
                        (const float4 *)c, ldc / 4, src, dst, graph, act, (float4 *)out, ldo / 4);
+    PSVAE_CHECK_LAUNCH(fn);
+    return PSVAE_OK;
+}
+
+extern "C" int psvae_pair_combine_bwd(int B, int F, const float *g_out, int ldg, const float *out, int ldo, int act,
+                                      const int32_t *src, const int32_t *dst, const int32_t *pair_ptr,
+                                      const int32_t *node_begin, const int32_t *node_end, float *g_ab, int ldab,
+                                      float *g_c, int ldc, void *stream) {
+    const char *fn = "psvae_pair_combine_bwd";
+    PSVAE_REQUIRE(B >= 0 && F > 0 && F % 4 == 0, PSVAE_EINVAL, "%s: F=%d must be a positive multiple of 4", fn, F);
+    PSVAE_REQUIRE(act == PSVAE_ACT_NONE || act == PSVAE_ACT_RELU, PSVAE_EINVAL, "%s: bad act %d", fn, act);
+    if (B == 0) return PSVAE_OK;
+    PSVAE_REQUIRE(pair_ptr && node_begin && node_end && g_ab && g_c && psvae_aligned16(g_ab) && psvae_aligned16(g_c) &&
+                      (g_out == nullptr || psvae_aligned16(g_out)) && (out == nullptr || psvae_aligned16(out)),
+                  PSVAE_EINVAL, "%s: null or misaligned operand", fn);
+    PSVAE_REQUIRE(ldg % 4 == 0 && ldg >= F && ldo % 4 == 0 && ldo >= F && ldab % 4 == 0 && ldab >= 2 * F && ldc % 4 == 0 &&
+                      ldc >= F, PSVAE_EINVAL, "%s: bad row stride", fn);
+    PSVAE_REQUIRE(act == PSVAE_ACT_NONE || out != nullptr || g_out == nullptr, PSVAE_EINVAL, "%s: the ReLU gate needs `out`", fn);
+    const int f4 = F / 4;
+    PSVAE_REQUIRE(f4 <= 1024, PSVAE_ETOOLARGE, "%s: F too wide", fn);
+    int slots = f4 >= 256 ? 1 : psvae_cdiv(256, f4);
+    int threads = psvae_cdiv(f4 * slots, 64) * 64;
+    if (threads > 1024) slots = 1024 / f4, threads = psvae_cdiv(f4 * slots, 64) * 64;
+    hipLaunchKernelGGL(pair_combine_bwd_kernel, dim3(B), dim3(threads), 0, (hipStream_t)stream, f4, slots,
+                       act == PSVAE_ACT_RELU ? 1 : 0, (const float4 *)g_out, ldg / 4, (const float4 *)out, ldo / 4, src, dst,
+                       pair_ptr, node_begin, node_end, (float4 *)g_ab, ldab / 4, (float4 *)g_c, ldc / 4);
     PSVAE_CHECK_LAUNCH(fn);
     return PSVAE_OK;
 }

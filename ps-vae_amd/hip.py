@@ -58,6 +58,8 @@ _SIGNATURES = {
     'psvae_link_ce_workspace_bytes': (_c_size, [_c_int]),
     'psvae_link_ce_fwd': (_c_int, [_c_int, _c_int, _c_int, _p, _c_int, _p, _p, _p, _p, _p, _p, _p, _p, _c_size, _p]),
     'psvae_link_ce_bwd_input': (_c_int, [_c_int, _c_int, _c_int, _p, _p, _p, _p, _c_int, _p]),
+    'psvae_pair_combine_bwd': (_c_int, [_c_int, _c_int, _p, _c_int, _p, _c_int, _c_int, _p, _p, _p, _p, _p, _p, _c_int, _p,
+                                        _c_int, _p]),
     'psvae_token_ce_workspace_bytes': (_c_size, [_c_int]),
     'psvae_token_ce_fwd': (_c_int, [_c_int, _c_int, _p, _c_i64, _p, _c_int, _p, _p, _p, _p, _c_size, _p]),
     'psvae_link_infer': (_c_int, [_c_int, _c_int, _p, _c_f32, _c_int, _p, _p, _p, _p]),
@@ -459,6 +461,18 @@ def pair_combine_fwd(a, b, c, src, dst, graph, out, relu=True):
     _check(lib().psvae_pair_combine_fwd(src.numel(), out.shape[1], pa, lda, pb, ldb, pc, ldc, ptr(src, torch.int32),
                                         ptr(dst, torch.int32), ptr(graph, torch.int32), 1 if relu else 0, po, ldo,
                                         _stream()), 'psvae_pair_combine_fwd')
+
+
+def pair_combine_bwd(g_out, out, relu, src, dst, pair_ptr, node_begin, node_end, g_ab, g_c):
+    B, F = g_c.shape
+    P = src.numel()
+    pg, ldg = _rows(g_out) if P else (None, F)
+    po, ldo = _rows(out) if P else (None, F)
+    pab, ldab = _rows(g_ab)
+    pc, ldc = _rows(g_c)
+    _check(lib().psvae_pair_combine_bwd(B, F, pg, ldg, po, ldo, 1 if relu else 0, ptr(src, torch.int32),
+                                        ptr(dst, torch.int32), ptr(pair_ptr, torch.int32), ptr(node_begin, torch.int32),
+                                        ptr(node_end, torch.int32), pab, ldab, pc, ldc, _stream()), 'psvae_pair_combine_bwd')
 
 
 def link_ce_fwd(hid, W, b, golden, logits, dlogits, loss, n_correct):

@@ -103,24 +103,27 @@ class VAEPieceDecoder(nn.Module):
         mlp, last = self.edge_predictor[0], self.edge_predictor[1]
         seq = mlp.seq
         H, L = node_embedding.shape[-1], z_vecs.shape[-1]
-        split_first = (golden is None and not torch.is_grad_enabled() and isinstance(seq, nn.Sequential)
-                       and len(seq) >= 4 and isinstance(seq[0], nn.Linear) and isinstance(seq[1], nn.ReLU)
-                       and isinstance(seq[-1], nn.Linear) and seq[0].bias is not None
+        split_first = (isinstance(seq, nn.Sequential) and len(seq) >= 4 and isinstance(seq[0], nn.Linear)
+                       and isinstance(seq[1], nn.ReLU) and isinstance(seq[-1], nn.Linear) and seq[0].bias is not None
                        and seq[0].in_features == 2 * H + L and seq[0].out_features % 4 == 0 and H % 4 == 0)
         if split_first:
-            # Inference over ALL candidate pairs (pairs >> atoms): the first layer's weight is cut at
-            # the [h_src | h_dst | z] blocks and applied once per atom / per molecule; per pair only
-            # a gather-add-ReLU remains, and the [P, 2H+L] feature rows are never formed.
+            # The first layer's weight is cut at the [h_src | h_dst | z] blocks and applied once per
+            # atom / per molecule (one product for both atom blocks, a small one for z); per pair only
+            # a gather-add-ReLU remains, and neither the [P, 2H+L] feature rows nor their gradient are
+            # ever formed.  In training P ~ V, so the arithmetic is the same; over ALL candidate pairs
+            # of generated molecules (pairs >> atoms) it is several times less.
             first = seq[0]
             w = first.weight
-            hu = ops.linear(node_embedding, w[:, :H])
-            hv = ops.linear(node_embedding, w[:, H:2 * H])
-            hz = ops.linear(z_vecs, w[:, 2 * H:], first.bias)
-            hid = torch.empty(len(pairs), first.out_features, dtype=torch.float32, device=w.device)
-            hip.pair_combine_fwd(hu, hv, hz, pairs.src, pairs.dst, pairs.graph, hid, relu=True)
+            w_nodes = torch.cat([w[:, :H], w[:, H:2 * H]], dim=0)      # [2F, H]: rows of Wa, then of Wb
+            huv = ops.linear(node_embedding, w_nodes)                  # [V, 2F]
+            hz = ops.linear(z_vecs, w[:, 2 * H:], first.bias)          # [B, F]
+            hid = ops.pair_combine(huv, hz, pairs, relu=True)
             hid = run_sequential(seq[2:-1], hid)
             weight, bias = ops.affine_merge(last.weight, last.bias, seq[-1].weight, seq[-1].bias)
-            return ops.linear(hid, weight, bias), None, None
+            if golden is None:
+                return ops.linear(hid, weight, bias), None, None
+            loss, logits, n_ok = ops.link_ce(hid, weight, bias, golden)
+            return logits, loss, n_ok
         feats = ops.pair_gather(node_embedding, z_vecs, pairs)
         if isinstance(seq, nn.Sequential) and len(seq) > 1 and isinstance(seq[-1], nn.Linear):
             # No activation sits between the MLP's output layer and the class layer, so the

@@ -612,6 +612,44 @@ def pair_gather(h, z, pairs):
     return _PairGather.apply(h, z, pairs)
 
 
+class _PairCombine(Function):
+    """act(ab[src][:F] + ab[dst][F:] + c[graph]) per candidate pair: the link predictor's first layer
+    after its weight has been split by input block, so that the [P, 2H+L] feature rows are never
+    formed - forward or backward."""
+
+    @staticmethod
+    def forward(ctx, ab, c, pairs, relu):
+        ab2, c2 = _rows2d(ab), _rows2d(c)
+        F = c2.shape[1]
+        if ab2.shape[1] != 2 * F:
+            raise ValueError(f'pair_combine: node rows of {ab2.shape[1]} columns, graph rows of {F}')
+        out = torch.empty(len(pairs), F, dtype=torch.float32, device=ab2.device)
+        hip.pair_combine_fwd(ab2[:, :F], ab2[:, F:], c2, pairs.src, pairs.dst, pairs.graph, out, relu=relu)
+        if relu and RELU_TRACE is not None:
+            RELU_TRACE.append(out.detach())
+        ctx.pairs, ctx.relu, ctx.rows = pairs, relu, ab2.shape[0]
+        ctx.save_for_backward(out if relu else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        out, = ctx.saved_tensors
+        pairs = ctx.pairs
+        g2 = g if (g.dtype == torch.float32 and g.stride(-1) == 1) else g.float().contiguous()
+        B, F = pairs.ptr.numel() - 1, g2.shape[1]
+        alloc = torch.empty if pairs.nodes.covers_all_rows else torch.zeros
+        g_ab = alloc(ctx.rows, 2 * F, dtype=torch.float32, device=g2.device)
+        g_c = torch.empty(B, F, dtype=torch.float32, device=g2.device)
+        hip.pair_combine_bwd(g2, out, ctx.relu, pairs.src, pairs.dst, pairs.ptr, pairs.nodes.begin, pairs.nodes.end,
+                             g_ab, g_c)
+        return g_ab, g_c, None, None
+
+
+def pair_combine(ab, c, pairs, relu=True):
+    """[P, F] rows act(ab[src[p]][:F] + ab[dst[p]][F:] + c[graph[p]]) for ab [V, 2F], c [B, F]."""
+    return _PairCombine.apply(ab, c, pairs, relu)
+
+
 # ------------------------------------------------------------------------ two Linears as one
 class _AffineMerge(Function):
     @staticmethod

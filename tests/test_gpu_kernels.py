@@ -508,6 +508,36 @@ def test_pair_gather_bwd_many_pairs_per_graph():
     close(zd.grad, z.grad, what='d pair / dz')
 
 
+@pytest.mark.parametrize('B,N,F,dense', [(5, 13, 328, 0.1), (2, 60, 36, 0.6), (3, 7, 8, 0.0)])
+def test_pair_combine_fwd_bwd(B, N, F, dense):
+    """relu(ab[src][:F] + ab[dst][F:] + c[graph]) per pair and its backward (gated sums into the node
+    and graph rows, in pair order) against autograd in float64: a training-sized case, one with more
+    pairs per graph than an LDS chunk, and one without any pair (all gradients zero)."""
+    from ps_vae_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(B * 100 + N)
+    sel = torch.rand(B, N, N, generator=g) < dense
+    ab = torch.randn(B * N, 2 * F, generator=g, dtype=torch.float64, requires_grad=True)
+    c = torch.randn(B, F, generator=g, dtype=torch.float64, requires_grad=True)
+    b, m, n = sel.nonzero(as_tuple=True)
+    if dense > 0.5:
+        assert (b == 0).sum() > 1024
+    want = torch.relu(ab[b * N + m][:, :F] + ab[b * N + n][:, F:] + c[b])
+    gy = torch.randn(want.shape, generator=g, dtype=torch.float64)
+    want.backward(gy)
+    pairs = ops.PairList.from_edge_select(sel.to(d))
+    abd, cd = ab.detach().float().to(d).requires_grad_(), c.detach().float().to(d).requires_grad_()
+    got = ops.pair_combine(abd, cd, pairs, relu=True)
+    got.backward(gy.float().to(d))
+    if want.numel():
+        close(got, want.detach(), what='pair_combine')
+    else:
+        assert got.shape == (0, F)
+    # (a pre-activation within rounding of zero could take the other side in float32: none does here)
+    close(abd.grad, ab.grad, what='d / d ab')
+    close(cd.grad, c.grad, what='d / d c')
+
+
 @pytest.mark.parametrize('P', [0, 1, 5, 4097])
 def test_link_ce_fwd_bwd(P):
     from ps_vae_amd import ops
