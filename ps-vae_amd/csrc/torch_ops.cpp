@@ -1,0 +1,173 @@
+// PyTorch custom operators (namespace `psvae`) over the C ABI of libpsvae_hip.so: the operators of
+// the training step's four kernel families - matrix product, message-passing aggregation (forward
+// and backward), pair combination (forward and backward) and the fused link loss - registered with
+// torch.library so that they are visible as torch.ops.psvae.* (profiler, graph tools) and called
+// without a Python-side pointer marshalling layer.  Each operator checks device / dtype / row
+// layout, takes PyTorch's current HIP stream, owns the per-stream workspace its entry point needs,
+// and turns a non-zero status into a c10::Error carrying psvae_last_error().  Host code only: the
+// kernels live in libpsvae_hip.so (include/psvae_hip.h).
+#include <ATen/ATen.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/library.h>
+
+#include <map>
+#include <mutex>
+#include <utility>
+
+#include "../../include/psvae_hip.h"
+
+namespace {
+
+using at::Tensor;
+using OptTensor = std::optional<Tensor>;
+
+void *cur_stream(const Tensor &t) {
+    TORCH_CHECK(t.is_cuda(), "psvae operators need GPU tensors (there is no CPU fallback)");
+    return (void *)c10::hip::getCurrentHIPStream(t.device().index()).stream();
+}
+
+void check(int rc, const char *name) { TORCH_CHECK(rc == 0, name, " failed with status ", rc, ": ", psvae_last_error()); }
+
+const float *f32(const Tensor &t, const char *what) {
+    TORCH_CHECK(t.is_cuda(), what, ": psvae operators need GPU tensors (there is no CPU fallback)");
+    TORCH_CHECK(t.scalar_type() == at::kFloat, what, ": expected float32, got ", t.scalar_type());
+    return t.const_data_ptr<float>();
+}
+const float *f32(const OptTensor &t, const char *what) { return t.has_value() && t->defined() ? f32(*t, what) : nullptr; }
+float *f32_mut(const Tensor &t, const char *what) { return const_cast<float *>(f32(t, what)); }
+float *f32_mut(const OptTensor &t, const char *what) { return const_cast<float *>(f32(t, what)); }
+
+const int32_t *i32(const Tensor &t, const char *what) {
+    TORCH_CHECK(t.is_cuda() && t.scalar_type() == at::kInt && t.is_contiguous(), what, ": expected a contiguous int32 GPU tensor");
+    return t.const_data_ptr<int32_t>();
+}
+const uint8_t *u8(const Tensor &t, const char *what) {
+    TORCH_CHECK(t.is_cuda() && t.scalar_type() == at::kByte && t.is_contiguous(), what, ": expected a contiguous uint8 GPU tensor");
+    return t.const_data_ptr<uint8_t>();
+}
+
+// row stride (in elements) of a 2-D tensor whose last dimension is contiguous
+int64_t row_stride(const Tensor &t, const char *what) {
+    TORCH_CHECK(t.dim() == 2 && (t.size(1) <= 1 || t.stride(1) == 1), what, ": need a 2-D tensor with contiguous rows");
+    return t.size(0) > 1 ? t.stride(0) : std::max<int64_t>(t.stride(0), t.size(1));
+}
+
+// A scratch buffer per (device, stream), grown on demand.  Kernels that reuse it are ordered by the
+// stream they are enqueued on; two streams never share one.
+Tensor workspace(size_t nbytes, const Tensor &like, void *stream) {
+    static std::mutex mu;
+    static std::map<std::pair<int, void *>, Tensor> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    Tensor &buf = cache[{like.device().index(), stream}];
+    if (!buf.defined() || (size_t)buf.numel() < nbytes)
+        buf = at::empty({(int64_t)std::max<size_t>(nbytes, 1u << 20)}, like.options().dtype(at::kByte));
+    return buf;
+}
+
+// C (+)= act(A B + bias): see psvae_gemm_f32 (operands addressed through element strides)
+void gemm(int64_t M, int64_t N, int64_t K, const Tensor &A, const OptTensor &amask, int64_t sa_m, int64_t sa_k,
+          const Tensor &B, int64_t sb_k, int64_t sb_n, Tensor C, int64_t ldc, const OptTensor &bias, OptTensor rowsum,
+          const OptTensor &cmask, bool relu, bool accumulate, int64_t split_k) {
+    void *s = cur_stream(C);
+    const size_t nbytes = psvae_gemm_f32_workspace_bytes((int)M, (int)N, (int)K, (int)split_k);
+    void *ws = nullptr;
+    Tensor hold;
+    if (nbytes) hold = workspace(nbytes, C, s), ws = hold.data_ptr();
+    check(psvae_gemm_f32((int)M, (int)N, (int)K, f32(A, "gemm A"), f32(amask, "gemm amask"), sa_m, sa_k, f32(B, "gemm B"), sb_k,
+                         sb_n, f32_mut(C, "gemm C"), ldc, f32(bias, "gemm bias"), f32_mut(rowsum, "gemm rowsum"),
+                         f32(cmask, "gemm cmask"), relu ? PSVAE_ACT_RELU : PSVAE_ACT_NONE, accumulate ? 1 : 0, (int)split_k, ws,
+                         nbytes, s),
+          "psvae_gemm_f32");
+}
+
+void gine_aggregate_fwd(const Tensor &x, const Tensor &table, const Tensor &row_ptr, const Tensor &col, const Tensor &cls,
+                        Tensor out) {
+    const char *fn = "psvae_gine_aggregate_fwd";
+    check(psvae_gine_aggregate_fwd((int)x.size(0), (int)x.size(1), (int)table.size(0), f32(x, fn), (int)row_stride(x, fn),
+                                   f32(table, fn), i32(row_ptr, fn), i32(col, fn), u8(cls, fn), f32_mut(out, fn),
+                                   (int)row_stride(out, fn), cur_stream(x)),
+          fn);
+}
+
+void gine_aggregate_bwd(const Tensor &x, const Tensor &table, const Tensor &g, const Tensor &t_row_ptr, const Tensor &t_col,
+                        const Tensor &t_cls, const OptTensor &add, Tensor g_x, Tensor g_table, bool accumulate_table) {
+    const char *fn = "psvae_gine_aggregate_bwd";
+    const int V = (int)x.size(0), H = (int)x.size(1), C = (int)table.size(0);
+    void *s = cur_stream(x);
+    const size_t nbytes = psvae_gine_aggregate_bwd_workspace_bytes(V, H, C);
+    void *ws = nullptr;
+    Tensor hold;
+    if (nbytes) hold = workspace(nbytes, x, s), ws = hold.data_ptr();
+    const bool has_add = add.has_value() && add->defined();
+    check(psvae_gine_aggregate_bwd(V, H, C, f32(x, fn), (int)row_stride(x, fn), f32(table, fn), f32(g, fn),
+                                   (int)row_stride(g, fn), i32(t_row_ptr, fn), i32(t_col, fn), u8(t_cls, fn),
+                                   f32(add, fn), has_add ? (int)row_stride(*add, fn) : H, f32_mut(g_x, fn),
+                                   (int)row_stride(g_x, fn), f32_mut(g_table, fn), accumulate_table ? 1 : 0, ws, nbytes, s),
+          fn);
+}
+
+void pair_combine_fwd(const Tensor &a, const Tensor &b, const Tensor &c, const Tensor &src, const Tensor &dst,
+                      const Tensor &graph, bool relu, Tensor out) {
+    const char *fn = "psvae_pair_combine_fwd";
+    check(psvae_pair_combine_fwd((int)src.numel(), (int)out.size(1), f32(a, fn), (int)row_stride(a, fn), f32(b, fn),
+                                 (int)row_stride(b, fn), f32(c, fn), (int)row_stride(c, fn), i32(src, fn), i32(dst, fn),
+                                 i32(graph, fn), relu ? PSVAE_ACT_RELU : PSVAE_ACT_NONE, f32_mut(out, fn),
+                                 (int)row_stride(out, fn), cur_stream(out)),
+          fn);
+}
+
+void pair_combine_bwd(const Tensor &g_out, const OptTensor &out, bool relu, const Tensor &src, const Tensor &dst,
+                      const Tensor &pair_ptr, const Tensor &node_begin, const Tensor &node_end, Tensor g_ab, Tensor g_c) {
+    const char *fn = "psvae_pair_combine_bwd";
+    const int B = (int)g_c.size(0), F = (int)g_c.size(1);
+    const bool any = src.numel() > 0;
+    const bool has_out = any && out.has_value() && out->defined();
+    check(psvae_pair_combine_bwd(B, F, any ? f32(g_out, fn) : nullptr, any ? (int)row_stride(g_out, fn) : F,
+                                 has_out ? f32(*out, fn) : nullptr, has_out ? (int)row_stride(*out, fn) : F,
+                                 relu ? PSVAE_ACT_RELU : PSVAE_ACT_NONE, i32(src, fn), i32(dst, fn), i32(pair_ptr, fn),
+                                 i32(node_begin, fn), i32(node_end, fn), f32_mut(g_ab, fn), (int)row_stride(g_ab, fn),
+                                 f32_mut(g_c, fn), (int)row_stride(g_c, fn), cur_stream(g_c)),
+          fn);
+}
+
+void link_ce_fwd(const Tensor &hid, const Tensor &W, const OptTensor &b, const Tensor &golden, Tensor logits, Tensor dlogits,
+                 Tensor loss, Tensor n_correct) {
+    const char *fn = "psvae_link_ce_fwd";
+    const int P = (int)hid.size(0), F = (int)hid.size(1);
+    void *s = cur_stream(W);
+    const size_t nbytes = psvae_link_ce_workspace_bytes(P);
+    Tensor hold = workspace(nbytes, W, s);
+    TORCH_CHECK(n_correct.is_cuda() && n_correct.scalar_type() == at::kInt, fn, ": n_correct must be an int32 GPU tensor");
+    check(psvae_link_ce_fwd(P, F, (int)W.size(0), P ? f32(hid, fn) : nullptr, P ? (int)row_stride(hid, fn) : F, f32(W, fn),
+                            f32(b, fn), P ? i32(golden, fn) : nullptr, f32_mut(logits, fn), f32_mut(dlogits, fn),
+                            f32_mut(loss, fn), n_correct.data_ptr<int32_t>(), hold.data_ptr(), nbytes, s),
+          fn);
+}
+
+void link_ce_bwd_input(const Tensor &dlogits, const Tensor &W, const Tensor &g_loss, Tensor g_hid) {
+    const char *fn = "psvae_link_ce_bwd_input";
+    const int P = (int)dlogits.size(0);
+    check(psvae_link_ce_bwd_input(P, (int)W.size(1), (int)dlogits.size(1), f32(dlogits, fn), f32(W, fn), f32(g_loss, fn),
+                                  P ? f32_mut(g_hid, fn) : nullptr, P ? (int)row_stride(g_hid, fn) : (int)W.size(1),
+                                  cur_stream(W)),
+          fn);
+}
+
+}  // namespace
+
+TORCH_LIBRARY(psvae, m) {
+    m.def("gemm(int M, int N, int K, Tensor A, Tensor? amask, int sa_m, int sa_k, Tensor B, int sb_k, int sb_n, "
+          "Tensor(a!) C, int ldc, Tensor? bias, Tensor(b!)? rowsum, Tensor? cmask, bool relu, bool accumulate, "
+          "int split_k) -> ()", &gemm);
+    m.def("gine_aggregate_fwd(Tensor x, Tensor table, Tensor row_ptr, Tensor col, Tensor cls, Tensor(a!) out) -> ()",
+          &gine_aggregate_fwd);
+    m.def("gine_aggregate_bwd(Tensor x, Tensor table, Tensor g, Tensor t_row_ptr, Tensor t_col, Tensor t_cls, Tensor? add, "
+          "Tensor(a!) g_x, Tensor(b!) g_table, bool accumulate_table) -> ()", &gine_aggregate_bwd);
+    m.def("pair_combine_fwd(Tensor a, Tensor b, Tensor c, Tensor src, Tensor dst, Tensor graph, bool relu, Tensor(a!) out) -> ()",
+          &pair_combine_fwd);
+    m.def("pair_combine_bwd(Tensor g_out, Tensor? out, bool relu, Tensor src, Tensor dst, Tensor pair_ptr, Tensor node_begin, "
+          "Tensor node_end, Tensor(a!) g_ab, Tensor(b!) g_c) -> ()", &pair_combine_bwd);
+    m.def("link_ce_fwd(Tensor hid, Tensor W, Tensor? b, Tensor golden, Tensor(a!) logits, Tensor(b!) dlogits, Tensor(c!) loss, "
+          "Tensor(d!) n_correct) -> ()", &link_ce_fwd);
+    m.def("link_ce_bwd_input(Tensor dlogits, Tensor W, Tensor g_loss, Tensor(a!) g_hid) -> ()", &link_ce_bwd_input);
+}

@@ -1,9 +1,12 @@
-"""ctypes binding of csrc/libpsvae_hip.so (C ABI declared in include/psvae_hip.h).
+"""Binding of csrc/libpsvae_hip.so (C ABI declared in include/psvae_hip.h).
 
-Thin by design: every wrapper checks that its tensors live on the GPU with the expected
-dtype / contiguity, passes raw device pointers plus PyTorch's current HIP stream, and turns
-a non-zero status into a RuntimeError carrying psvae_last_error().  There is no fallback:
-without the library, or with a CPU tensor, the call raises.
+Two routes, both thin.  The operators the training step spends its launches on - matrix product,
+message-passing aggregation, pair combination, link loss - are PyTorch custom operators
+(torch.ops.psvae.*, registered with torch.library by csrc/libpsvae_torch.so over the same C ABI).
+Every other entry point is bound with ctypes: the wrapper checks that its tensors live on the GPU
+with the expected dtype / contiguity, passes raw device pointers plus PyTorch's current HIP stream,
+and turns a non-zero status into a RuntimeError carrying psvae_last_error().  There is no
+fallback: without the libraries, or with a CPU tensor, the call raises.
 """
 import ctypes
 import os
@@ -12,6 +15,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('PSVAE_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libpsvae_hip.so')
+TORCH_OPS_PATH = os.path.join(_HERE, 'csrc', 'libpsvae_torch.so')
 
 _c_int, _c_i64, _c_size = ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
 _c_f32, _c_f64, _c_ll, _p = ctypes.c_float, ctypes.c_double, ctypes.c_longlong, ctypes.c_void_p
@@ -91,6 +95,39 @@ def lib():
         _lib = handle
     return _lib
 
+
+_ops = None
+
+
+def ops():
+    """torch.ops.psvae (the operators csrc/libpsvae_torch.so registers); raises if it is not built.
+    With PSVAE_HIP_LIB set (an A/B build of the kernel library) the operator library, which is
+    linked to the in-tree kernels, is bypassed: these calls then take the ctypes route too."""
+    global _ops
+    if _ops is None:
+        if not os.path.exists(TORCH_OPS_PATH):
+            raise RuntimeError(f'{TORCH_OPS_PATH} is missing: build it with `make -C {os.path.dirname(TORCH_OPS_PATH)}` '
+                               '(or __graft_entry__.build()); there is no CPU fallback')
+        lib()                                  # the kernel library first: the operator library links to it
+        torch.ops.load_library(TORCH_OPS_PATH)
+        _ops = _Overloads(torch.ops.psvae)
+    return _ops
+
+
+class _Overloads:
+    """The `.default` overload of every operator, looked up once: calling an overload directly skips
+    the per-call overload resolution of torch.ops.<ns>.<name>(...)."""
+
+    def __init__(self, namespace):
+        self._namespace = namespace
+
+    def __getattr__(self, name):
+        fn = getattr(self._namespace, name).default
+        setattr(self, name, fn)
+        return fn
+
+
+_CTYPES_ONLY = bool(os.environ.get('PSVAE_HIP_LIB'))
 
 CALLS = 0   # C-ABI calls made so far (bench.py reports calls per step)
 
@@ -240,12 +277,18 @@ def roofline_report(prof, hbm_peak_gbs, mfma_peak_tflops, traffic=None):
 # --------------------------------------------------------------------------- raw calls
 def gemm(M, N, K, A, sa_m, sa_k, B, sb_k, sb_n, C, ldc, bias=None, relu=False, accumulate=False,
          amask=None, split_k=0, rowsum=None, cmask=None):
-    L = lib()
-    nbytes = L.psvae_gemm_f32_workspace_bytes(M, N, K, split_k)
-    ws = workspace(nbytes, C.device) if nbytes else None
     tag = None
     if PROFILE is not None:
         tag = (M, N, K, 'k' if sa_k == 1 else 'm', 'k' if sb_k == 1 else 'n', amask is not None, rowsum is not None)
+    if not _CTYPES_ONLY:
+        global CALLS
+        CALLS += 1
+        with _Prof('gemm_f32_kernel', 2.0 * M * N * K, tag):
+            ops().gemm(M, N, K, A, amask, sa_m, sa_k, B, sb_k, sb_n, C, ldc, bias, rowsum, cmask, relu, accumulate, split_k)
+        return
+    L = lib()
+    nbytes = L.psvae_gemm_f32_workspace_bytes(M, N, K, split_k)
+    ws = workspace(nbytes, C.device) if nbytes else None
     with _Prof('gemm_f32_kernel', 2.0 * M * N * K, tag):
         rc = L.psvae_gemm_f32(M, N, K, ptr(A, torch.float32), ptr(amask, torch.float32), sa_m, sa_k,
                               ptr(B, torch.float32), sb_k, sb_n, ptr(C, torch.float32), ldc,
@@ -288,6 +331,12 @@ def colsum(x, out, mask=None, accumulate=False):
 
 def gine_aggregate_fwd(x, table, row_ptr, col, cls, out):
     V, H = x.shape
+    if not _CTYPES_ONLY:
+        global CALLS
+        CALLS += 1
+        with _Prof('gine_aggregate_fwd_kernel', aggregate_bytes(V, col.numel(), H)):
+            ops().gine_aggregate_fwd(x, table, row_ptr, col, cls, out)
+        return
     px, ldx = _rows(x)
     po, ldo = _rows(out)
     with _Prof('gine_aggregate_fwd_kernel', aggregate_bytes(V, col.numel(), H)):
@@ -298,8 +347,14 @@ def gine_aggregate_fwd(x, table, row_ptr, col, cls, out):
 
 
 def gine_aggregate_bwd(x, table, g, t_row_ptr, t_col, t_cls, g_x, g_table, add=None, accumulate_table=False):
-    L = lib()
     V, H = x.shape
+    if not _CTYPES_ONLY:
+        global CALLS
+        CALLS += 1
+        with _Prof('gine_aggregate_bwd_kernel', aggregate_bytes(V, t_col.numel(), H, backward=True)):
+            ops().gine_aggregate_bwd(x, table, g, t_row_ptr, t_col, t_cls, add, g_x, g_table, accumulate_table)
+        return
+    L = lib()
     C = table.shape[0]
     px, ldx = _rows(x)
     pg, ldg = _rows(g)
@@ -454,6 +509,10 @@ def pair_gather_bwd(g_feats, src, dst, pair_ptr, node_begin, node_end, g_h, g_z)
 
 
 def pair_combine_fwd(a, b, c, src, dst, graph, out, relu=True):
+    if not _CTYPES_ONLY:
+        global CALLS
+        CALLS += 1
+        return ops().pair_combine_fwd(a, b, c, src, dst, graph, relu, out)
     pa, lda = _rows(a)
     pb, ldb = _rows(b)
     pc, ldc = _rows(c)
@@ -464,6 +523,10 @@ def pair_combine_fwd(a, b, c, src, dst, graph, out, relu=True):
 
 
 def pair_combine_bwd(g_out, out, relu, src, dst, pair_ptr, node_begin, node_end, g_ab, g_c):
+    if not _CTYPES_ONLY:
+        global CALLS
+        CALLS += 1
+        return ops().pair_combine_bwd(g_out, out, relu, src, dst, pair_ptr, node_begin, node_end, g_ab, g_c)
     B, F = g_c.shape
     P = src.numel()
     pg, ldg = _rows(g_out) if P else (None, F)
@@ -476,6 +539,10 @@ def pair_combine_bwd(g_out, out, relu, src, dst, pair_ptr, node_begin, node_end,
 
 
 def link_ce_fwd(hid, W, b, golden, logits, dlogits, loss, n_correct):
+    if not _CTYPES_ONLY:
+        global CALLS
+        CALLS += 1
+        return ops().link_ce_fwd(hid, W, b, golden, logits, dlogits, loss, n_correct)
     L = lib()
     P, F = hid.shape
     ph, ldh = _rows(hid) if P else (None, F)
@@ -488,6 +555,10 @@ def link_ce_fwd(hid, W, b, golden, logits, dlogits, loss, n_correct):
 
 
 def link_ce_bwd_input(dlogits, W, g_loss, g_hid):
+    if not _CTYPES_ONLY:
+        global CALLS
+        CALLS += 1
+        return ops().link_ce_bwd_input(dlogits, W, g_loss, g_hid)
     P, C = dlogits.shape
     pg, ldg = _rows(g_hid) if P else (None, W.shape[1])
     _check(lib().psvae_link_ce_bwd_input(P, W.shape[1], C, ptr(dlogits, torch.float32), ptr(W, torch.float32),

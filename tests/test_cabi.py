@@ -121,3 +121,18 @@ def test_rejected_arguments_return_codes_without_touching_the_gpu():
     # link loss / inference helpers
     assert L.psvae_link_infer(0, 4, null, 0.5, 0, null, null, null, null) == 0
     assert ETOOLARGE == -2
+
+
+def test_torch_operator_library_registers_its_operators():
+    """csrc/libpsvae_torch.so loads and registers the operators of the training step under
+    torch.ops.psvae; on a CPU tensor they raise instead of computing anything."""
+    import torch
+    from ps_vae_amd import hip
+    ops = hip.ops()
+    names = ['gemm', 'gine_aggregate_fwd', 'gine_aggregate_bwd', 'pair_combine_fwd', 'pair_combine_bwd',
+             'link_ce_fwd', 'link_ce_bwd_input']
+    for name in names:
+        assert getattr(ops, name)._schema.name == f'psvae::{name}'
+    x = torch.zeros(4, 4)
+    with pytest.raises(RuntimeError, match='GPU tensors'):
+        ops.gemm(4, 4, 4, x, None, 4, 1, x, 1, 4, torch.zeros(4, 4), 4, None, None, None, False, False, 1)
