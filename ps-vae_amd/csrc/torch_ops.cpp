@@ -153,6 +153,129 @@ void link_ce_bwd_input(const Tensor &dlogits, const Tensor &W, const Tensor &g_l
           fn);
 }
 
+// ---- the smaller entry points of the training step: same conventions, no workspace unless noted
+const float *f32c(const Tensor &t, const char *what) {   // contiguous
+    TORCH_CHECK(t.is_contiguous(), what, ": expected a contiguous tensor");
+    return f32(t, what);
+}
+const float *f32c(const OptTensor &t, const char *what) { return t.has_value() && t->defined() ? f32c(*t, what) : nullptr; }
+
+void segment_sum_fwd(const Tensor &x, const Tensor &seg_begin, const Tensor &seg_end, Tensor out) {
+    const char *fn = "psvae_segment_sum_fwd";
+    check(psvae_segment_sum_fwd((int)out.size(0), (int)x.size(1), f32(x, fn), (int)row_stride(x, fn), i32(seg_begin, fn),
+                                i32(seg_end, fn), f32_mut(out, fn), (int)row_stride(out, fn), cur_stream(out)), fn);
+}
+
+void segment_sum_bwd(const Tensor &g_out, const Tensor &seg_begin, const Tensor &seg_end, Tensor g_x) {
+    const char *fn = "psvae_segment_sum_bwd";
+    check(psvae_segment_sum_bwd((int)g_out.size(0), (int)g_out.size(1), f32(g_out, fn), (int)row_stride(g_out, fn),
+                                i32(seg_begin, fn), i32(seg_end, fn), f32_mut(g_x, fn), (int)row_stride(g_x, fn),
+                                cur_stream(g_x)), fn);
+}
+
+void rsample_kl_fwd(const Tensor &mean, const Tensor &lv_pre, const Tensor &eps, Tensor z, Tensor kl) {
+    const char *fn = "psvae_rsample_kl_fwd";
+    check(psvae_rsample_kl_fwd((int)mean.size(0), (int)mean.size(1), f32c(mean, fn), f32c(lv_pre, fn), f32c(eps, fn),
+                               const_cast<float *>(f32c(z, fn)), f32_mut(kl, fn), cur_stream(z)), fn);
+}
+
+void rsample_kl_bwd(const Tensor &mean, const Tensor &lv_pre, const Tensor &eps, const OptTensor &g_z, const OptTensor &g_kl,
+                    Tensor g_mean, Tensor g_lv_pre) {
+    const char *fn = "psvae_rsample_kl_bwd";
+    check(psvae_rsample_kl_bwd((int)mean.size(0), (int)mean.size(1), f32c(mean, fn), f32c(lv_pre, fn), f32c(eps, fn),
+                               f32c(g_z, fn), f32(g_kl, fn), const_cast<float *>(f32c(g_mean, fn)),
+                               const_cast<float *>(f32c(g_lv_pre, fn)), cur_stream(g_mean)), fn);
+}
+
+void token_ce_fwd(const Tensor &logits, const Tensor &gold, int64_t ignore_index, Tensor dlogits, Tensor loss, Tensor counts) {
+    const char *fn = "psvae_token_ce_fwd";
+    const int R = (int)logits.size(0), V = (int)logits.size(1);
+    void *s = cur_stream(loss);
+    const size_t nbytes = psvae_token_ce_workspace_bytes(R);
+    Tensor hold = workspace(nbytes, loss, s);
+    TORCH_CHECK(counts.is_cuda() && counts.scalar_type() == at::kInt, fn, ": counts must be an int32 GPU tensor");
+    check(psvae_token_ce_fwd(R, V, R ? f32(logits, fn) : nullptr, R ? row_stride(logits, fn) : V, R ? i32(gold, fn) : nullptr,
+                             (int)ignore_index, R ? const_cast<float *>(f32c(dlogits, fn)) : nullptr, f32_mut(loss, fn),
+                             counts.data_ptr<int32_t>(), hold.data_ptr(), nbytes, s), fn);
+}
+
+void embed_trans_fwd(const Tensor &x, const Tensor &xp, const Tensor &xq, int64_t n_atom, int64_t n_piece, int64_t n_pos,
+                     const Tensor &T, Tensor out) {
+    const char *fn = "psvae_embed_trans_fwd";
+    TORCH_CHECK(T.dim() == 2 && T.size(0) == n_atom + n_piece + n_pos && T.size(1) == out.size(1), fn,
+                ": T must be a [n_atom + n_piece + n_pos, H] table");
+    TORCH_CHECK(x.numel() == xp.numel() && x.numel() == xq.numel() && x.numel() == out.size(0), fn,
+                ": id vectors and output rows differ in length");
+    check(psvae_embed_trans_fwd((int)x.numel(), (int)out.size(1), i32(x, fn), i32(xp, fn), i32(xq, fn), (int)n_atom,
+                                (int)n_piece, (int)n_pos, f32c(T, fn), f32_mut(out, fn), (int)row_stride(out, fn),
+                                cur_stream(out)), fn);
+}
+
+void embed_atom_onehot(const Tensor &x, const Tensor &xp, const Tensor &xq, int64_t n_atom, int64_t n_piece, int64_t n_pos,
+                       Tensor out) {
+    const char *fn = "psvae_embed_atom_onehot";
+    check(psvae_embed_atom_onehot((int)x.numel(), i32(x, fn), i32(xp, fn), i32(xq, fn), (int)n_atom, (int)n_piece, (int)n_pos,
+                                  const_cast<float *>(f32c(out, fn)), (int)out.size(1), cur_stream(out)), fn);
+}
+
+void embedding_fwd(const Tensor &ids, const Tensor &table, Tensor out) {
+    const char *fn = "psvae_embedding_fwd";
+    check(psvae_embedding_fwd((int)ids.numel(), (int)table.size(1), (int)table.size(0), i32(ids, fn), f32c(table, fn),
+                              const_cast<float *>(f32c(out, fn)), cur_stream(out)), fn);
+}
+
+void onehot(const Tensor &ids, Tensor out) {
+    const char *fn = "psvae_onehot_f32";
+    check(psvae_onehot_f32((int)ids.numel(), i32(ids, fn), const_cast<float *>(f32c(out, fn)), (int)out.size(1),
+                           cur_stream(out)), fn);
+}
+
+void affine_merge_fwd(const Tensor &w_last, const OptTensor &b_last, const Tensor &w_out, const OptTensor &b_out, Tensor w_eff,
+                      Tensor b_eff) {
+    const char *fn = "psvae_affine_merge_fwd";
+    check(psvae_affine_merge_fwd((int)w_last.size(0), (int)w_last.size(1), (int)w_out.size(1), f32c(w_last, fn),
+                                 f32c(b_last, fn), f32c(w_out, fn), f32c(b_out, fn), const_cast<float *>(f32c(w_eff, fn)),
+                                 const_cast<float *>(f32c(b_eff, fn)), cur_stream(w_eff)), fn);
+}
+
+void affine_merge_bwd(const Tensor &w_last, const Tensor &w_out, const OptTensor &b_out, const Tensor &g_w_eff,
+                      const Tensor &g_b_eff, Tensor g_w_last, Tensor g_w_out, OptTensor g_b_out) {
+    const char *fn = "psvae_affine_merge_bwd";
+    check(psvae_affine_merge_bwd((int)w_last.size(0), (int)w_last.size(1), (int)w_out.size(1), f32c(w_last, fn),
+                                 f32c(w_out, fn), f32c(b_out, fn), f32c(g_w_eff, fn), f32c(g_b_eff, fn),
+                                 const_cast<float *>(f32c(g_w_last, fn)), const_cast<float *>(f32c(g_w_out, fn)),
+                                 const_cast<float *>(f32c(g_b_out, fn)), cur_stream(g_w_last)), fn);
+}
+
+void colsum(const Tensor &x, const OptTensor &mask, Tensor out, bool accumulate) {
+    const char *fn = "psvae_colsum_f32";
+    const int M = (int)x.size(0), N = (int)x.size(1);
+    const int64_t ld = row_stride(x, fn);
+    TORCH_CHECK(!(mask.has_value() && mask->defined()) || row_stride(*mask, fn) == ld, fn, ": mask must have the row stride of x");
+    void *s = cur_stream(out);
+    const size_t nbytes = psvae_colsum_workspace_bytes(M, N);
+    void *ws = nullptr;
+    Tensor hold;
+    if (nbytes) hold = workspace(nbytes, out, s), ws = hold.data_ptr();
+    check(psvae_colsum_f32(M, N, f32(x, fn), f32(mask, fn), ld, f32_mut(out, fn), accumulate ? 1 : 0, ws, nbytes, s), fn);
+}
+
+void gru_seq_fwd(const Tensor &gi, const Tensor &h0, const Tensor &w_hh, const OptTensor &b_hh, Tensor hall, Tensor gates,
+                 Tensor ghn) {
+    const char *fn = "psvae_gru_seq_fwd";
+    check(psvae_gru_seq_fwd((int)gi.size(0), (int)gi.size(1), (int)gi.size(2) / 3, f32c(gi, fn), f32c(h0, fn), f32c(w_hh, fn),
+                            f32c(b_hh, fn), const_cast<float *>(f32c(hall, fn)), const_cast<float *>(f32c(gates, fn)),
+                            const_cast<float *>(f32c(ghn, fn)), cur_stream(hall)), fn);
+}
+
+void gru_seq_bwd(const Tensor &gates, const Tensor &ghn, const Tensor &hall, const Tensor &g_out, const Tensor &w_hh_t,
+                 Tensor dgi, Tensor dgh, Tensor dh0) {
+    const char *fn = "psvae_gru_seq_bwd";
+    check(psvae_gru_seq_bwd((int)gates.size(0), (int)gates.size(1), (int)gates.size(2) / 3, f32c(gates, fn), f32c(ghn, fn),
+                            f32c(hall, fn), f32c(g_out, fn), f32c(w_hh_t, fn), const_cast<float *>(f32c(dgi, fn)),
+                            const_cast<float *>(f32c(dgh, fn)), const_cast<float *>(f32c(dh0, fn)), cur_stream(dgi)), fn);
+}
+
 }  // namespace
 
 TORCH_LIBRARY(psvae, m) {
@@ -170,4 +293,26 @@ TORCH_LIBRARY(psvae, m) {
     m.def("link_ce_fwd(Tensor hid, Tensor W, Tensor? b, Tensor golden, Tensor(a!) logits, Tensor(b!) dlogits, Tensor(c!) loss, "
           "Tensor(d!) n_correct) -> ()", &link_ce_fwd);
     m.def("link_ce_bwd_input(Tensor dlogits, Tensor W, Tensor g_loss, Tensor(a!) g_hid) -> ()", &link_ce_bwd_input);
+    m.def("segment_sum_fwd(Tensor x, Tensor seg_begin, Tensor seg_end, Tensor(a!) out) -> ()", &segment_sum_fwd);
+    m.def("segment_sum_bwd(Tensor g_out, Tensor seg_begin, Tensor seg_end, Tensor(a!) g_x) -> ()", &segment_sum_bwd);
+    m.def("rsample_kl_fwd(Tensor mean, Tensor lv_pre, Tensor eps, Tensor(a!) z, Tensor(b!) kl) -> ()", &rsample_kl_fwd);
+    m.def("rsample_kl_bwd(Tensor mean, Tensor lv_pre, Tensor eps, Tensor? g_z, Tensor? g_kl, Tensor(a!) g_mean, "
+          "Tensor(b!) g_lv_pre) -> ()", &rsample_kl_bwd);
+    m.def("token_ce_fwd(Tensor logits, Tensor gold, int ignore_index, Tensor(a!) dlogits, Tensor(b!) loss, Tensor(c!) counts) -> ()",
+          &token_ce_fwd);
+    m.def("embed_trans_fwd(Tensor x, Tensor xp, Tensor xq, int n_atom, int n_piece, int n_pos, Tensor T, Tensor(a!) out) -> ()",
+          &embed_trans_fwd);
+    m.def("embed_atom_onehot(Tensor x, Tensor xp, Tensor xq, int n_atom, int n_piece, int n_pos, Tensor(a!) out) -> ()",
+          &embed_atom_onehot);
+    m.def("embedding_fwd(Tensor ids, Tensor table, Tensor(a!) out) -> ()", &embedding_fwd);
+    m.def("onehot(Tensor ids, Tensor(a!) out) -> ()", &onehot);
+    m.def("affine_merge_fwd(Tensor w_last, Tensor? b_last, Tensor w_out, Tensor? b_out, Tensor(a!) w_eff, Tensor(b!) b_eff) -> ()",
+          &affine_merge_fwd);
+    m.def("affine_merge_bwd(Tensor w_last, Tensor w_out, Tensor? b_out, Tensor g_w_eff, Tensor g_b_eff, Tensor(a!) g_w_last, "
+          "Tensor(b!) g_w_out, Tensor(c!)? g_b_out) -> ()", &affine_merge_bwd);
+    m.def("colsum(Tensor x, Tensor? mask, Tensor(a!) out, bool accumulate) -> ()", &colsum);
+    m.def("gru_seq_fwd(Tensor gi, Tensor h0, Tensor w_hh, Tensor? b_hh, Tensor(a!) hall, Tensor(b!) gates, Tensor(c!) ghn) -> ()",
+          &gru_seq_fwd);
+    m.def("gru_seq_bwd(Tensor gates, Tensor ghn, Tensor hall, Tensor g_out, Tensor w_hh_t, Tensor(a!) dgi, Tensor(b!) dgh, "
+          "Tensor(c!) dh0) -> ()", &gru_seq_bwd);
 }

@@ -88,7 +88,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f'{LIB_PATH} is missing: build it with `make -C {os.path.dirname(LIB_PATH)}` '
                                '(or __graft_entry__.build()); there is no CPU fallback')
-        handle = ctypes.CDLL(LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(handle, name)
             fn.restype, fn.argtypes = res, args
@@ -101,8 +101,8 @@ _ops = None
 
 def ops():
     """torch.ops.psvae (the operators csrc/libpsvae_torch.so registers); raises if it is not built.
-    With PSVAE_HIP_LIB set (an A/B build of the kernel library) the operator library, which is
-    linked to the in-tree kernels, is bypassed: these calls then take the ctypes route too."""
+    The kernel library is loaded first, so the operator library binds to that one (also when
+    PSVAE_HIP_LIB names an A/B build of it: the dependency is resolved by its soname)."""
     global _ops
     if _ops is None:
         if not os.path.exists(TORCH_OPS_PATH):
@@ -127,14 +127,16 @@ class _Overloads:
         return fn
 
 
-_CTYPES_ONLY = bool(os.environ.get('PSVAE_HIP_LIB'))
+def _count():
+    global CALLS
+    CALLS += 1
+
 
 CALLS = 0   # C-ABI calls made so far (bench.py reports calls per step)
 
 
 def _check(rc, name):
-    global CALLS
-    CALLS += 1
+    _count()
     if rc != 0:
         msg = lib().psvae_last_error().decode(errors='replace')
         raise RuntimeError(f'{name} failed with status {rc}: {msg}')
@@ -280,95 +282,38 @@ def gemm(M, N, K, A, sa_m, sa_k, B, sb_k, sb_n, C, ldc, bias=None, relu=False, a
     tag = None
     if PROFILE is not None:
         tag = (M, N, K, 'k' if sa_k == 1 else 'm', 'k' if sb_k == 1 else 'n', amask is not None, rowsum is not None)
-    if not _CTYPES_ONLY:
-        global CALLS
-        CALLS += 1
-        with _Prof('gemm_f32_kernel', 2.0 * M * N * K, tag):
-            ops().gemm(M, N, K, A, amask, sa_m, sa_k, B, sb_k, sb_n, C, ldc, bias, rowsum, cmask, relu, accumulate, split_k)
-        return
-    L = lib()
-    nbytes = L.psvae_gemm_f32_workspace_bytes(M, N, K, split_k)
-    ws = workspace(nbytes, C.device) if nbytes else None
+    _count()
     with _Prof('gemm_f32_kernel', 2.0 * M * N * K, tag):
-        rc = L.psvae_gemm_f32(M, N, K, ptr(A, torch.float32), ptr(amask, torch.float32), sa_m, sa_k,
-                              ptr(B, torch.float32), sb_k, sb_n, ptr(C, torch.float32), ldc,
-                              ptr(bias, torch.float32), ptr(rowsum, torch.float32), ptr(cmask, torch.float32),
-                              1 if relu else 0,
-                              1 if accumulate else 0, split_k, ptr(ws), nbytes, _stream())
-    _check(rc, 'psvae_gemm_f32')
+        ops().gemm(M, N, K, A, amask, sa_m, sa_k, B, sb_k, sb_n, C, ldc, bias, rowsum, cmask, relu, accumulate, split_k)
 
 
 def affine_merge_fwd(w_last, b_last, w_out, b_out, w_eff, b_eff):
-    C, J = w_last.shape
-    K = w_out.shape[1]
-    _check(lib().psvae_affine_merge_fwd(C, J, K, ptr(w_last, torch.float32), ptr(b_last, torch.float32),
-                                        ptr(w_out, torch.float32), ptr(b_out, torch.float32),
-                                        ptr(w_eff, torch.float32), ptr(b_eff, torch.float32), _stream()),
-           'psvae_affine_merge_fwd')
+    _count()
+    ops().affine_merge_fwd(w_last, b_last, w_out, b_out, w_eff, b_eff)
 
 
 def affine_merge_bwd(w_last, w_out, b_out, g_w_eff, g_b_eff, g_w_last, g_w_out, g_b_out):
-    C, J = w_last.shape
-    K = w_out.shape[1]
-    _check(lib().psvae_affine_merge_bwd(C, J, K, ptr(w_last, torch.float32), ptr(w_out, torch.float32),
-                                        ptr(b_out, torch.float32), ptr(g_w_eff, torch.float32),
-                                        ptr(g_b_eff, torch.float32), ptr(g_w_last, torch.float32),
-                                        ptr(g_w_out, torch.float32), ptr(g_b_out, torch.float32), _stream()),
-           'psvae_affine_merge_bwd')
+    _count()
+    ops().affine_merge_bwd(w_last, w_out, b_out, g_w_eff, g_b_eff, g_w_last, g_w_out, g_b_out)
 
 
 def colsum(x, out, mask=None, accumulate=False):
-    L = lib()
-    M, N = x.shape
-    px, ld = _rows(x)
-    if mask is not None and _rows(mask)[1] != ld:
-        raise ValueError('mask must have the row stride of x')
-    nbytes = L.psvae_colsum_workspace_bytes(M, N)
-    ws = workspace(nbytes, x.device) if nbytes else None
-    _check(L.psvae_colsum_f32(M, N, px, ptr(mask, torch.float32), ld, ptr(out, torch.float32),
-                              1 if accumulate else 0, ptr(ws), nbytes, _stream()), 'psvae_colsum_f32')
+    _count()
+    ops().colsum(x, mask, out, accumulate)
 
 
 def gine_aggregate_fwd(x, table, row_ptr, col, cls, out):
     V, H = x.shape
-    if not _CTYPES_ONLY:
-        global CALLS
-        CALLS += 1
-        with _Prof('gine_aggregate_fwd_kernel', aggregate_bytes(V, col.numel(), H)):
-            ops().gine_aggregate_fwd(x, table, row_ptr, col, cls, out)
-        return
-    px, ldx = _rows(x)
-    po, ldo = _rows(out)
+    _count()
     with _Prof('gine_aggregate_fwd_kernel', aggregate_bytes(V, col.numel(), H)):
-        rc = lib().psvae_gine_aggregate_fwd(V, H, table.shape[0], px, ldx, ptr(table, torch.float32),
-                                            ptr(row_ptr, torch.int32), ptr(col, torch.int32),
-                                            ptr(cls, torch.uint8), po, ldo, _stream())
-    _check(rc, 'psvae_gine_aggregate_fwd')
+        ops().gine_aggregate_fwd(x, table, row_ptr, col, cls, out)
 
 
 def gine_aggregate_bwd(x, table, g, t_row_ptr, t_col, t_cls, g_x, g_table, add=None, accumulate_table=False):
     V, H = x.shape
-    if not _CTYPES_ONLY:
-        global CALLS
-        CALLS += 1
-        with _Prof('gine_aggregate_bwd_kernel', aggregate_bytes(V, t_col.numel(), H, backward=True)):
-            ops().gine_aggregate_bwd(x, table, g, t_row_ptr, t_col, t_cls, add, g_x, g_table, accumulate_table)
-        return
-    L = lib()
-    C = table.shape[0]
-    px, ldx = _rows(x)
-    pg, ldg = _rows(g)
-    pgx, ldgx = _rows(g_x)
-    padd, ldadd = _rows(add) if add is not None else (None, H)
-    nbytes = L.psvae_gine_aggregate_bwd_workspace_bytes(V, H, C)
-    ws = workspace(nbytes, x.device) if nbytes else None
+    _count()
     with _Prof('gine_aggregate_bwd_kernel', aggregate_bytes(V, t_col.numel(), H, backward=True)):
-        rc = L.psvae_gine_aggregate_bwd(V, H, C, px, ldx, ptr(table, torch.float32), pg, ldg,
-                                        ptr(t_row_ptr, torch.int32), ptr(t_col, torch.int32),
-                                        ptr(t_cls, torch.uint8), padd, ldadd, pgx, ldgx,
-                                        ptr(g_table, torch.float32), 1 if accumulate_table else 0,
-                                        ptr(ws), nbytes, _stream())
-    _check(rc, 'psvae_gine_aggregate_bwd')
+        ops().gine_aggregate_bwd(x, table, g, t_row_ptr, t_col, t_cls, add, g_x, g_table, accumulate_table)
 
 
 def gine_aggregate_bwd_noalloc(x, table, g, t_row_ptr, t_col, t_cls, g_x, g_table, add=None, accumulate_table=False):
@@ -395,9 +340,8 @@ def embed_atom_fwd(x, xp, xq, ea, ep, eq, out):
 
 
 def embed_atom_onehot(x, xp, xq, n_atom, n_piece, n_pos, out):
-    _check(lib().psvae_embed_atom_onehot(x.numel(), ptr(x, torch.int32), ptr(xp, torch.int32), ptr(xq, torch.int32),
-                                         n_atom, n_piece, n_pos, ptr(out, torch.float32), out.stride(0), _stream()),
-           'psvae_embed_atom_onehot')
+    _count()
+    ops().embed_atom_onehot(x, xp, xq, n_atom, n_piece, n_pos, out)
 
 
 def embed_atom_bwd(x, xp, xq, g, ga, gp, gq):
@@ -408,55 +352,39 @@ def embed_atom_bwd(x, xp, xq, g, ga, gp, gq):
 
 
 def embedding_fwd(ids, table, out):
-    _check(lib().psvae_embedding_fwd(ids.numel(), table.shape[1], table.shape[0], ptr(ids, torch.int32),
-                                     ptr(table, torch.float32), ptr(out, torch.float32), _stream()),
-           'psvae_embedding_fwd')
+    _count()
+    ops().embedding_fwd(ids, table, out)
 
 
 def onehot(ids, out):
-    _check(lib().psvae_onehot_f32(ids.numel(), ptr(ids, torch.int32), ptr(out, torch.float32), out.stride(0), _stream()),
-           'psvae_onehot_f32')
+    _count()
+    ops().onehot(ids, out)
 
 
 def embed_trans_fwd(x, xp, xq, sizes, T, out):
     na, npc, nq = sizes
-    po, ldo = _rows(out)
-    if T.shape[0] != na + npc + nq or T.shape[1] != out.shape[1] or not T.is_contiguous():
-        raise ValueError('embed_trans_fwd: T must be a contiguous [n_atom + n_piece + n_pos, H] table')
-    if not (x.numel() == xp.numel() == xq.numel() == out.shape[0]):
-        raise ValueError('embed_trans_fwd: id vectors and output rows differ in length')
-    _check(lib().psvae_embed_trans_fwd(x.numel(), out.shape[1], ptr(x, torch.int32), ptr(xp, torch.int32),
-                                       ptr(xq, torch.int32), na, npc, nq, ptr(T, torch.float32), po, ldo, _stream()),
-           'psvae_embed_trans_fwd')
+    _count()
+    ops().embed_trans_fwd(x, xp, xq, na, npc, nq, T, out)
 
 
 def segment_sum_fwd(x, seg_begin, seg_end, out):
-    px, ldx = _rows(x)
-    po, ldo = _rows(out)
-    _check(lib().psvae_segment_sum_fwd(out.shape[0], x.shape[1], px, ldx, ptr(seg_begin, torch.int32),
-                                       ptr(seg_end, torch.int32), po, ldo, _stream()), 'psvae_segment_sum_fwd')
+    _count()
+    ops().segment_sum_fwd(x, seg_begin, seg_end, out)
 
 
 def segment_sum_bwd(g_out, seg_begin, seg_end, g_x):
-    pg, ldg = _rows(g_out)
-    px, ldx = _rows(g_x)
-    _check(lib().psvae_segment_sum_bwd(g_out.shape[0], g_out.shape[1], pg, ldg, ptr(seg_begin, torch.int32),
-                                       ptr(seg_end, torch.int32), px, ldx, _stream()), 'psvae_segment_sum_bwd')
+    _count()
+    ops().segment_sum_bwd(g_out, seg_begin, seg_end, g_x)
 
 
 def rsample_kl_fwd(mean, lv_pre, eps, z, kl):
-    B, Ld = mean.shape
-    _check(lib().psvae_rsample_kl_fwd(B, Ld, ptr(mean, torch.float32), ptr(lv_pre, torch.float32),
-                                      ptr(eps, torch.float32), ptr(z, torch.float32), ptr(kl, torch.float32),
-                                      _stream()), 'psvae_rsample_kl_fwd')
+    _count()
+    ops().rsample_kl_fwd(mean, lv_pre, eps, z, kl)
 
 
 def rsample_kl_bwd(mean, lv_pre, eps, g_z, g_kl, g_mean, g_lv_pre):
-    B, Ld = mean.shape
-    _check(lib().psvae_rsample_kl_bwd(B, Ld, ptr(mean, torch.float32), ptr(lv_pre, torch.float32),
-                                      ptr(eps, torch.float32), ptr(g_z, torch.float32), ptr(g_kl, torch.float32),
-                                      ptr(g_mean, torch.float32), ptr(g_lv_pre, torch.float32), _stream()),
-           'psvae_rsample_kl_bwd')
+    _count()
+    ops().rsample_kl_bwd(mean, lv_pre, eps, g_z, g_kl, g_mean, g_lv_pre)
 
 
 def gru_cell_fwd(gi, gh, h_prev, h, gates):
@@ -477,18 +405,13 @@ GRU_SEQ_MAX_H = 256
 
 
 def gru_seq_fwd(gi, h0, w_hh, b_hh, hall, gates, ghn):
-    T, B, H3 = gi.shape
-    f = torch.float32
-    _check(lib().psvae_gru_seq_fwd(T, B, H3 // 3, ptr(gi, f), ptr(h0, f), ptr(w_hh, f), ptr(b_hh, f), ptr(hall, f),
-                                   ptr(gates, f), ptr(ghn, f), _stream()), 'psvae_gru_seq_fwd')
+    _count()
+    ops().gru_seq_fwd(gi, h0, w_hh, b_hh, hall, gates, ghn)
 
 
 def gru_seq_bwd(gates, ghn, hall, g_out, w_hh_t, dgi, dgh, dh0):
-    T, B, H3 = gates.shape
-    f = torch.float32
-    _check(lib().psvae_gru_seq_bwd(T, B, H3 // 3, ptr(gates, f), ptr(ghn, f), ptr(hall, f), ptr(g_out, f),
-                                   ptr(w_hh_t, f), ptr(dgi, f), ptr(dgh, f), ptr(dh0, f), _stream()),
-           'psvae_gru_seq_bwd')
+    _count()
+    ops().gru_seq_bwd(gates, ghn, hall, g_out, w_hh_t, dgi, dgh, dh0)
 
 
 def pair_gather_fwd(h, z, src, dst, graph, feats):
@@ -509,72 +432,29 @@ def pair_gather_bwd(g_feats, src, dst, pair_ptr, node_begin, node_end, g_h, g_z)
 
 
 def pair_combine_fwd(a, b, c, src, dst, graph, out, relu=True):
-    if not _CTYPES_ONLY:
-        global CALLS
-        CALLS += 1
-        return ops().pair_combine_fwd(a, b, c, src, dst, graph, relu, out)
-    pa, lda = _rows(a)
-    pb, ldb = _rows(b)
-    pc, ldc = _rows(c)
-    po, ldo = _rows(out)
-    _check(lib().psvae_pair_combine_fwd(src.numel(), out.shape[1], pa, lda, pb, ldb, pc, ldc, ptr(src, torch.int32),
-                                        ptr(dst, torch.int32), ptr(graph, torch.int32), 1 if relu else 0, po, ldo,
-                                        _stream()), 'psvae_pair_combine_fwd')
+    _count()
+    ops().pair_combine_fwd(a, b, c, src, dst, graph, relu, out)
 
 
 def pair_combine_bwd(g_out, out, relu, src, dst, pair_ptr, node_begin, node_end, g_ab, g_c):
-    if not _CTYPES_ONLY:
-        global CALLS
-        CALLS += 1
-        return ops().pair_combine_bwd(g_out, out, relu, src, dst, pair_ptr, node_begin, node_end, g_ab, g_c)
-    B, F = g_c.shape
-    P = src.numel()
-    pg, ldg = _rows(g_out) if P else (None, F)
-    po, ldo = _rows(out) if P else (None, F)
-    pab, ldab = _rows(g_ab)
-    pc, ldc = _rows(g_c)
-    _check(lib().psvae_pair_combine_bwd(B, F, pg, ldg, po, ldo, 1 if relu else 0, ptr(src, torch.int32),
-                                        ptr(dst, torch.int32), ptr(pair_ptr, torch.int32), ptr(node_begin, torch.int32),
-                                        ptr(node_end, torch.int32), pab, ldab, pc, ldc, _stream()), 'psvae_pair_combine_bwd')
+    _count()
+    ops().pair_combine_bwd(g_out, out, relu, src, dst, pair_ptr, node_begin, node_end, g_ab, g_c)
 
 
 def link_ce_fwd(hid, W, b, golden, logits, dlogits, loss, n_correct):
-    if not _CTYPES_ONLY:
-        global CALLS
-        CALLS += 1
-        return ops().link_ce_fwd(hid, W, b, golden, logits, dlogits, loss, n_correct)
-    L = lib()
-    P, F = hid.shape
-    ph, ldh = _rows(hid) if P else (None, F)
-    nbytes = L.psvae_link_ce_workspace_bytes(P)
-    ws = workspace(nbytes, W.device)
-    _check(L.psvae_link_ce_fwd(P, F, W.shape[0], ph, ldh, ptr(W, torch.float32), ptr(b, torch.float32),
-                               ptr(golden, torch.int32), ptr(logits, torch.float32), ptr(dlogits, torch.float32),
-                               ptr(loss, torch.float32), ptr(n_correct, torch.int32), ptr(ws), nbytes, _stream()),
-           'psvae_link_ce_fwd')
+    _count()
+    ops().link_ce_fwd(hid, W, b, golden, logits, dlogits, loss, n_correct)
 
 
 def link_ce_bwd_input(dlogits, W, g_loss, g_hid):
-    if not _CTYPES_ONLY:
-        global CALLS
-        CALLS += 1
-        return ops().link_ce_bwd_input(dlogits, W, g_loss, g_hid)
-    P, C = dlogits.shape
-    pg, ldg = _rows(g_hid) if P else (None, W.shape[1])
-    _check(lib().psvae_link_ce_bwd_input(P, W.shape[1], C, ptr(dlogits, torch.float32), ptr(W, torch.float32),
-                                         ptr(g_loss, torch.float32), pg, ldg, _stream()), 'psvae_link_ce_bwd_input')
+    _count()
+    ops().link_ce_bwd_input(dlogits, W, g_loss, g_hid)
 
 
 def token_ce_fwd(logits, gold, ignore_index, dlogits, loss, counts):
     """logits [R,V] (rows of any stride), gold int32 [R] -> dlogits [R,V], loss f32[2], counts i32[2]."""
-    L = lib()
-    R, V = logits.shape
-    pl, ld = _rows(logits) if R else (None, V)
-    nbytes = L.psvae_token_ce_workspace_bytes(R)
-    ws = workspace(nbytes, loss.device)
-    _check(L.psvae_token_ce_fwd(R, V, pl, ld, ptr(gold, torch.int32), int(ignore_index), ptr(dlogits, torch.float32),
-                                ptr(loss, torch.float32), ptr(counts, torch.int32), ptr(ws), nbytes, _stream()),
-           'psvae_token_ce_fwd')
+    _count()
+    ops().token_ce_fwd(logits, gold, int(ignore_index), dlogits, loss, counts)
 
 
 def link_infer(logits, add_edge_th, none_bond, conf, etype, keep):

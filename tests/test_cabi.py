@@ -130,7 +130,9 @@ def test_torch_operator_library_registers_its_operators():
     from ps_vae_amd import hip
     ops = hip.ops()
     names = ['gemm', 'gine_aggregate_fwd', 'gine_aggregate_bwd', 'pair_combine_fwd', 'pair_combine_bwd',
-             'link_ce_fwd', 'link_ce_bwd_input']
+             'link_ce_fwd', 'link_ce_bwd_input', 'segment_sum_fwd', 'segment_sum_bwd', 'rsample_kl_fwd',
+             'rsample_kl_bwd', 'token_ce_fwd', 'embed_trans_fwd', 'embed_atom_onehot', 'embedding_fwd', 'onehot',
+             'affine_merge_fwd', 'affine_merge_bwd', 'colsum', 'gru_seq_fwd', 'gru_seq_bwd']
     for name in names:
         assert getattr(ops, name)._schema.name == f'psvae::{name}'
     x = torch.zeros(4, 4)
