@@ -7,7 +7,8 @@
 One step = collate a batch of synthetic ZINC-shaped molecules (already packed in HBM) on the
 GPU, forward, backward, gradient all-reduce (N > 1), global-norm clip, Adam.  Workload:
 BASELINE.json configs[2] ("synthetic ZINC-shaped graphs, batch 4096") per GPU, weak scaling.
-Rank 0 prints ONE JSON line (see README / DESIGN.md for the fields).
+Rank 0 prints ONE JSON line: metric / value / ms_per_step, the roofline of the dominant kernels from event
+brackets on a few timed steps, sub-records for batch 32 and 10k-molecule generation, and a CPU baseline.
 """
 import argparse
 import gc
