@@ -143,3 +143,32 @@ def test_losses_and_gradients_add_over_half_batches(workload, tokenizer):
         # identical terms summed in a different order (the K chunks of a weight-gradient product are
         # cut from the row count, so the full batch and its halves chain their fp32 partial sums differently)
         assert err <= 2e-5 * scale + 1e-30, f'{k}: {err / max(scale, 1e-30):.2e} of the largest entry'
+
+
+def test_train_step_repeats_bit_for_bit(workload, tokenizer):
+    """The same 4096-molecule batch, uniforms and eps through forward + backward three times, two
+    streams on: every loss and every gradient repeats bit for bit.  No kernel on the path uses
+    atomics or a timing-dependent order of summation, so any difference is a race (a tile read
+    before its load had landed showed up exactly like this, as a 1e-5 wobble of one gradient)."""
+    from ps_vae_amd.data.collate import collate_packed
+    from ps_vae_amd.pl_models import PSVAEModel
+    from ps_vae_amd.utils.nn_utils import build_config, default_args
+    packed, dpacked, uniforms = workload
+    torch.manual_seed(13)
+    model = PSVAEModel(build_config(default_args(), tokenizer), tokenizer).to(dev())
+    assert model.two_streams
+    eps = torch.randn(B, model.decoder.latent_dim, generator=torch.Generator().manual_seed(6)).to(dev())
+    runs = []
+    for _ in range(3):
+        batch = collate_packed(dpacked, np.arange(B), uniforms=uniforms, atom_pad=tokenizer.atom_pad_idx(),
+                               piece_pad=tokenizer.pad_idx(), reference_layout=False)
+        model.zero_grad(set_to_none=True)
+        pl, (rec, piece, edge, kl) = model(batch, eps=eps)
+        model.weighted_loss(pl, rec, kl).backward()
+        torch.cuda.synchronize()
+        runs.append((torch.stack([pl, rec, piece, edge, kl]).detach().clone(),
+                     {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}))
+    for losses, grads in runs[1:]:
+        assert torch.equal(losses, runs[0][0]), (losses, runs[0][0])
+        for k, g in grads.items():
+            assert torch.equal(g, runs[0][1][k]), f'{k} differs between two runs of the same step'
