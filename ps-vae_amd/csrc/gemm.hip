@@ -217,7 +217,7 @@ int resolve_split(int M, int N, int K, int split_k) {
     const long long tiles = prefer_2x2(M, N + 1) ? psvae_cdiv(M, 64) : (long long)psvae_cdiv(M, 128) * nc;
     if (tiles >= 192) return 1;
     long long s = 512 / tiles;
-    const long long by_k = K / 64;    // at least two k-tiles of work per split
+    const long long by_k = K / 128;   // at least four k-tiles of work per split
     if (s > by_k) s = by_k;
     return s < 1 ? 1 : (int)s;
 }
