@@ -327,37 +327,41 @@ __global__ void pair_gather_bwd_kernel(int h4, int l4, int slots, const float4 *
 // Backward of pair_combine_fwd with a = ab[:, :F], b = ab[:, F:] (one [V, 2F] matrix): the gradient
 // of a pair's row, gated by the ReLU derivative (out > 0) when act is ReLU, is added to the a block of
 // its source node, the b block of its destination node and the row of its graph.  One workgroup per
-// graph, as pair_gather_bwd: thread (slot, c) owns column c of nodes slot, slot+slots, ... and walks
-// the staged pairs in order, so every sum runs in pair order.
-__global__ void pair_combine_bwd_kernel(int f4, int slots, int relu, const float4 *__restrict__ g_out, int ldg4,
+// graph.  The gated rows of up to `chunk` pairs are staged in LDS by all threads at once (independent
+// 16-byte loads); then thread (slot, c) owns column c of nodes slot, slot+slots, ... and walks the
+// staged pairs in order, so every sum runs in pair order and only touches LDS.
+constexpr int PAIR_ROWS_MAX = 256, PAIR_ROWS_LDS_BYTES = 32 * 1024;
+__global__ void pair_combine_bwd_kernel(int f4, int slots, int chunk, int relu, const float4 *__restrict__ g_out, int ldg4,
                                         const float4 *__restrict__ out, int ldo4, const int32_t *__restrict__ src,
                                         const int32_t *__restrict__ dst, const int32_t *__restrict__ pair_ptr,
                                         const int32_t *__restrict__ node_begin, const int32_t *__restrict__ node_end,
                                         float4 *__restrict__ g_ab, int ldab4, float4 *__restrict__ g_c, int ldc4) {
-    __shared__ int s_src[PAIR_CHUNK], s_dst[PAIR_CHUNK];
+    extern __shared__ float4 s_rows[];   // [chunk][f4]
+    __shared__ int s_src[PAIR_ROWS_MAX], s_dst[PAIR_ROWS_MAX];
     const int b = blockIdx.x;
     const int p0 = pair_ptr[b], p1 = pair_ptr[b + 1];
     const int n0 = node_begin[b], n1 = node_end[b];
     const int c = threadIdx.x % f4, slot = threadIdx.x / f4;
     const bool active = slot < slots;
-    auto row = [&](int p, int col) {
-        float4 g = g_out[(long long)p * ldg4 + col];
-        if (relu) {
-            const float4 o = out[(long long)p * ldo4 + col];
-            g.x = o.x > 0.f ? g.x : 0.f, g.y = o.y > 0.f ? g.y : 0.f, g.z = o.z > 0.f ? g.z : 0.f, g.w = o.w > 0.f ? g.w : 0.f;
-        }
-        return g;
-    };
     float4 cacc = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool cthread = (int)threadIdx.x < f4;
     bool first = true;
     int pc = p0;
     do {   // runs once even without pairs so that the outputs are written
-        const int cnt = min(PAIR_CHUNK, p1 - pc);
+        const int cnt = min(chunk, p1 - pc);
         __syncthreads();
         for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
             s_src[i] = src[pc + i] - n0;
             s_dst[i] = dst[pc + i] - n0;
+        }
+        for (int idx = threadIdx.x; idx < cnt * f4; idx += blockDim.x) {
+            const int i = idx / f4, col = idx - i * f4;
+            float4 g = g_out[(long long)(pc + i) * ldg4 + col];
+            if (relu) {
+                const float4 o = out[(long long)(pc + i) * ldo4 + col];
+                g.x = o.x > 0.f ? g.x : 0.f, g.y = o.y > 0.f ? g.y : 0.f, g.z = o.z > 0.f ? g.z : 0.f, g.w = o.w > 0.f ? g.w : 0.f;
+            }
+            s_rows[idx] = g;
         }
         __syncthreads();
         if (active) {
@@ -368,7 +372,7 @@ __global__ void pair_combine_bwd_kernel(int f4, int slots, int relu, const float
                 for (int i = 0; i < cnt; ++i) {
                     const bool is_src = s_src[i] == j, is_dst = s_dst[i] == j;
                     if (is_src || is_dst) {
-                        const float4 m = row(pc + i, c);
+                        const float4 m = s_rows[i * f4 + c];
                         if (is_src) acc_a = add4(acc_a, m);
                         if (is_dst) acc_b = add4(acc_b, m);
                     }
@@ -377,7 +381,7 @@ __global__ void pair_combine_bwd_kernel(int f4, int slots, int relu, const float
             }
         }
         if (cthread)
-            for (int i = 0; i < cnt; ++i) cacc = add4(cacc, row(pc + i, threadIdx.x));
+            for (int i = 0; i < cnt; ++i) cacc = add4(cacc, s_rows[i * f4 + threadIdx.x]);
         first = false;
         pc += cnt;
     } while (pc < p1);
@@ -623,12 +627,23 @@ __global__ void colsum_partial_kernel(int M, int N, int rows_per_block, const fl
     }
 }
 
-__global__ void colsum_finish_kernel(int N, int n_part, const float *__restrict__ partial, float *__restrict__ out,
-                                     int accumulate) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
+// 64 columns per workgroup; the four waves each add a quarter of the partial rows (in row order,
+// eight loads in flight) and wave 0 adds the four sums in wave order.
+__global__ __launch_bounds__(256) void colsum_finish_kernel(int N, int n_part, const float *__restrict__ partial,
+                                                            float *__restrict__ out, int accumulate) {
+    __shared__ float sh[3][64];
+    const int q = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int n = blockIdx.x * 64 + l;
+    const int per = (n_part + 3) >> 2, b0 = q * per, b1 = min(n_part, b0 + per);
     float s = 0.f;
-    for (int b = 0; b < n_part; ++b) s += partial[(long long)b * N + n];
+    if (n < N) {
+#pragma unroll 8
+        for (int b = b0; b < b1; ++b) s += partial[(long long)b * N + n];
+    }
+    if (q) sh[q - 1][l] = s;
+    __syncthreads();
+    if (q || n >= N) return;
+    s = ((s + sh[0][l]) + sh[1][l]) + sh[2][l];
     out[n] = accumulate ? out[n] + s : s;
 }
 
@@ -845,7 +860,10 @@ extern "C" int psvae_pair_combine_bwd(int B, int F, const float *g_out, int ldg,
     int slots = f4 >= 256 ? 1 : psvae_cdiv(256, f4);
     int threads = psvae_cdiv(f4 * slots, 64) * 64;
     if (threads > 1024) slots = 1024 / f4, threads = psvae_cdiv(f4 * slots, 64) * 64;
-    hipLaunchKernelGGL(pair_combine_bwd_kernel, dim3(B), dim3(threads), 0, (hipStream_t)stream, f4, slots,
+    int chunk = PAIR_ROWS_LDS_BYTES / (F * (int)sizeof(float));
+    chunk = chunk < 1 ? 1 : (chunk > PAIR_ROWS_MAX ? PAIR_ROWS_MAX : chunk);
+    hipLaunchKernelGGL(pair_combine_bwd_kernel, dim3(B), dim3(threads), (size_t)chunk * F * sizeof(float),
+                       (hipStream_t)stream, f4, slots, chunk,
                        act == PSVAE_ACT_RELU ? 1 : 0, (const float4 *)g_out, ldg / 4, (const float4 *)out, ldo / 4, src, dst,
                        pair_ptr, node_begin, node_end, (float4 *)g_ab, ldab / 4, (float4 *)g_c, ldc / 4);
     PSVAE_CHECK_LAUNCH(fn);
@@ -994,7 +1012,7 @@ extern "C" int psvae_colsum_f32(int M, int N, const float *x, const float *mask,
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(blocks), dim3(threads), 0, s, M, N, rpb, x, mask, (long long)ldx,
                        (float *)workspace);
     PSVAE_CHECK_LAUNCH("psvae_colsum_f32");
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3(psvae_cdiv(N, 256)), dim3(256), 0, s, N, blocks,
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3(psvae_cdiv(N, 64)), dim3(256), 0, s, N, blocks,
                        (const float *)workspace, out, accumulate);
     PSVAE_CHECK_LAUNCH("psvae_colsum_f32 (finish)");
     return PSVAE_OK;

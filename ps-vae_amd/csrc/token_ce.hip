@@ -5,7 +5,7 @@
 // and sum of exponentials across its lanes and writes the row of softmax(x) - onehot(gold) (zeros
 // for an ignored row) - the gradient up to the factor g_loss / count.  Loss, token count and the
 // count of rows whose first maximum is the gold label are summed per workgroup and then by one
-// workgroup in workgroup order: the result does not depend on timing.
+// workgroup in a fixed order: the result does not depend on timing.
 #include "common.h"
 
 namespace {
@@ -76,12 +76,28 @@ __global__ __launch_bounds__(CE_THREADS) void token_ce_kernel(int R, int V, cons
     }
 }
 
-__global__ __launch_bounds__(64) void token_ce_finish_kernel(int blocks, const CePartial *__restrict__ part,
-                                                             float *__restrict__ loss, int *__restrict__ counts) {
-    if (threadIdx.x != 0) return;
+// One workgroup: thread t sums partials t, t + 256, ... in that order, then the 256 sums are added
+// pairwise through LDS in a fixed tree: the result depends on the number of partials only.
+__global__ __launch_bounds__(CE_THREADS) void token_ce_finish_kernel(int blocks, const CePartial *__restrict__ part,
+                                                                     float *__restrict__ loss, int *__restrict__ counts) {
+    __shared__ float sh_loss[CE_THREADS];
+    __shared__ int sh_n[CE_THREADS], sh_ok[CE_THREADS];
+    const int t = threadIdx.x;
     float s = 0.f;
     int n = 0, ok = 0;
-    for (int b = 0; b < blocks; ++b) s += part[b].loss, n += part[b].count, ok += part[b].correct;
+#pragma unroll 8
+    for (int b = t; b < blocks; b += CE_THREADS) {
+        const CePartial p = part[b];
+        s += p.loss, n += p.count, ok += p.correct;
+    }
+    sh_loss[t] = s, sh_n[t] = n, sh_ok[t] = ok;
+    __syncthreads();
+    for (int half = CE_THREADS / 2; half > 0; half >>= 1) {
+        if (t < half) sh_loss[t] += sh_loss[t + half], sh_n[t] += sh_n[t + half], sh_ok[t] += sh_ok[t + half];
+        __syncthreads();
+    }
+    if (t != 0) return;
+    s = sh_loss[0], n = sh_n[0], ok = sh_ok[0];
     loss[0] = s / (float)n;          // no live row: 0 / 0 = NaN, as torch's mean over nothing
     loss[1] = 1.f / (float)n;
     counts[0] = n, counts[1] = ok;
@@ -120,7 +136,7 @@ extern "C" int psvae_token_ce_fwd(int R, int V, const float *logits, int64_t ld,
     else PSVAE_CE(16);
 #undef PSVAE_CE
     PSVAE_CHECK_LAUNCH("psvae_token_ce_fwd");
-    hipLaunchKernelGGL(token_ce_finish_kernel, dim3(1), dim3(64), 0, s, blocks, part, loss, counts);
+    hipLaunchKernelGGL(token_ce_finish_kernel, dim3(1), dim3(CE_THREADS), 0, s, blocks, part, loss, counts);
     PSVAE_CHECK_LAUNCH("psvae_token_ce_fwd (finish)");
     return PSVAE_OK;
 }

@@ -87,9 +87,17 @@ class PSVAEModel(nn.Module):
                                   return_accu=return_accu, eps=eps)
             props = batch['props']
         pred_prop = self.predictor(z)
-        golden = props.reshape(batch_size, -1)[:, self.config['selected_properties']].float()
+        golden = props.reshape(batch_size, -1).index_select(1, self._selected_props(props.device)).float()
         pred_loss = self.pred_loss(pred_prop, golden)
         return pred_loss, res
+
+    def _selected_props(self, device):
+        # the column indices as a device tensor made once: indexing with the Python list would
+        # copy it to the device on every step (and cannot be captured in a HIP graph)
+        idx = getattr(self, '_prop_idx', None)
+        if idx is None or idx.device != device:
+            idx = self._prop_idx = torch.tensor(self.config['selected_properties'], dtype=torch.int64, device=device)
+        return idx
 
     def cal_beta(self):
         step = self.global_step
