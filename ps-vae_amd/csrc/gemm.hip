@@ -222,6 +222,21 @@ int resolve_split(int M, int N, int K, int split_k) {
     return s < 1 ? 1 : (int)s;
 }
 
+// Products below this many panel workgroups take the 64 x 64 tiles; their K split leaves at least
+// four 64-deep k-tiles per workgroup and stops at one workgroup per CU (never more splits than
+// resolve_split grants: the workspace is sized from that).
+#ifndef PSVAE_TILE64_BELOW
+#define PSVAE_TILE64_BELOW 128   // (the -D override exists for A/B builds only)
+#endif
+constexpr int TILE64_BELOW_BLOCKS = PSVAE_TILE64_BELOW;
+int tile64_split(int M, int n_ext, int K) {
+    const long long tiles = (long long)psvae_cdiv(M, 64) * psvae_cdiv(n_ext, 64);
+    long long s = 256 / tiles;
+    const long long by_k = K / 256;
+    if (s > by_k) s = by_k;
+    return s < 1 ? 1 : (int)s;
+}
+
 bool vec_ok(const float *p, long long s_major) {
     return p == nullptr || (psvae_aligned16(p) && s_major % 4 == 0);
 }
@@ -274,13 +289,29 @@ extern "C" int psvae_gemm_f32(int M, int N, int K, const float *A, const float *
         PSVAE_CHECK_LAUNCH("psvae_gemm_f32 (tall-K reduce)");
         return PSVAE_OK;
     }
+    const int n_ext = N + (rowsum ? 1 : 0);
+    const bool a_kc = (sa_k == 1), b_kc = (sb_k == 1);
+    // The panel kernel needs unit stride along one axis of each operand, 16-byte aligned
+    // bases / major strides, and the vectorised extent to be a multiple of 4.
+    const bool a_vec = (a_kc ? (K % 4 == 0 && vec_ok(A, sa_m)) : (sa_m == 1 && M % 4 == 0 && vec_ok(A, sa_k))) &&
+                       (amask == nullptr || psvae_aligned16(amask));
+    const bool b_vec = b_kc ? (K % 4 == 0 && vec_ok(B, sb_n)) : (sb_n == 1 && N % 4 == 0 && vec_ok(B, sb_k));
+    const bool panel = a_vec && b_vec && (!rowsum || !b_kc) && M >= 32;
+    int nc = 1, bn = 32, tn = 1;
+    if (panel) panel_shape(n_ext, nc, bn, tn);
+    const bool two_by_two = panel && !a_kc && !b_kc && prefer_2x2(M, n_ext);
+    const int split_asked = split_k;
     split_k = resolve_split(M, N, K, split_k);
-    int k_chunk = psvae_cdiv(psvae_cdiv(K, split_k), 32) * 32;
-    if (k_chunk == 0) k_chunk = 32;
+    // 64 x 64 tiles where the panels (with their K split) would leave the chip mostly idle
+    const bool tile64 = panel && !two_by_two && (long long)psvae_cdiv(M, 128) * nc * split_k < TILE64_BELOW_BLOCKS;
+    if (tile64 && split_asked == 0) split_k = tile64_split(M, n_ext, K);
+    const int kq = tile64 ? TILE64_BK : 32;
+    int k_chunk = psvae_cdiv(psvae_cdiv(K, split_k), kq) * kq;
+    if (k_chunk == 0) k_chunk = kq;
     split_k = K > 0 ? psvae_cdiv(K, k_chunk) : 1;
     PSVAE_REQUIRE(split_k <= 65535, PSVAE_ETOOLARGE, "psvae_gemm_f32: split_k %d too large", split_k);
     if (split_k > 1) {
-        PSVAE_REQUIRE(workspace != nullptr && workspace_bytes >= psvae_gemm_f32_workspace_bytes(M, N, K, split_k),
+        PSVAE_REQUIRE(workspace != nullptr && workspace_bytes >= (size_t)split_k * (size_t)M * (size_t)(N + 4) * sizeof(float),
                       PSVAE_EWORKSPACE, "psvae_gemm_f32: workspace too small for split_k %d", split_k);
     }
     GemmArgs g;
@@ -293,20 +324,13 @@ extern "C" int psvae_gemm_f32(int M, int N, int K, const float *A, const float *
     g.B = B, g.sb_k = sb_k, g.sb_n = sb_n;
     g.C = C, g.ldc = ldc, g.bias = bias, g.rowsum = rowsum, g.cmask = cmask, g.act = act;
     g.accumulate = accumulate, g.split_k = split_k, g.k_chunk = k_chunk, g.ws = (float *)workspace, g.tail_begin = K;
-    const bool a_kc = (sa_k == 1), b_kc = (sb_k == 1);
-
-    // The panel kernel needs unit stride along one axis of each operand, 16-byte aligned
-    // bases / major strides, and the vectorised extent to be a multiple of 4.
-    const bool a_vec = (a_kc ? (K % 4 == 0 && vec_ok(A, sa_m)) : (sa_m == 1 && M % 4 == 0 && vec_ok(A, sa_k))) &&
-                       (amask == nullptr || psvae_aligned16(amask));
-    const bool b_vec = b_kc ? (K % 4 == 0 && vec_ok(B, sb_n)) : (sb_n == 1 && N % 4 == 0 && vec_ok(B, sb_k));
-    bool panel = a_vec && b_vec && (!rowsum || !b_kc) && M >= 32;
-    int nc = 1, bn = 32, tn = 1;
-    if (panel) panel_shape(g.n_ext, nc, bn, tn);
-
-    if (panel) {
+    if (tile64) {
+        g.nt_m = psvae_cdiv(M, 64), g.nt_n = psvae_cdiv(g.n_ext, 64), g.bn = 64, g.wn = 2;
+        const long long blocks = (long long)psvae_cdiv((long long)g.nt_m * split_k, 8) * 8 * g.nt_n;
+        launch_tile64(g, a_kc, b_kc, dim3((unsigned)blocks), s);
+    } else if (panel) {
         g.nt_m = psvae_cdiv(M, 128), g.nt_n = nc, g.bn = bn, g.wn = 1;
-        if (!a_kc && !b_kc && prefer_2x2(M, g.n_ext)) {
+        if (two_by_two) {
             g.wn = 2, g.nt_m = psvae_cdiv(M, 64), g.nt_n = 1, g.bn = 320;
             tn = 5;
         }

@@ -35,7 +35,7 @@ struct GemmArgs {
     int act;
     int accumulate;
     int split_k;
-    int k_chunk;          // multiple of 32
+    int k_chunk;          // multiple of the kernel's k-tile depth
     float *ws;            // [split_k][M][ws_ld] when split_k > 1
     int ws_ld;            // n_ext rounded up to a multiple of 4
     int c_vec;            // C (and ws) rows may be written 16 bytes at a time; 2: and byte offsets fit 32 bits
@@ -84,6 +84,13 @@ __device__ __forceinline__ bool tile_of_block(const GemmArgs &g, int &tile_m, in
 // variants compile in parallel).
 template <int TN, int BK>
 void launch_panel(const GemmArgs &g, bool a_kc, bool b_kc, dim3 grid, hipStream_t s);
+
+// ---- 64 x 64 tiles for small products (tile64_inst.hip)
+#ifndef PSVAE_TILE64_BK
+#define PSVAE_TILE64_BK 64
+#endif
+constexpr int TILE64_BK = PSVAE_TILE64_BK;
+void launch_tile64(const GemmArgs &g, bool a_kc, bool b_kc, dim3 grid, hipStream_t s);
 
 // ---- tall-K weight-gradient kernel (gemm_tallk.hip)
 constexpr int TK_THREADS = 512, TK_BK = 16, TK_LDA = 304, TK_LDB = 176, TK_T = 5, TK_MAX = 304, TK_STAGES = 3;

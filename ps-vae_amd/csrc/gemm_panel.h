@@ -86,7 +86,8 @@ struct TileLoader {
 };
 
 // WN = 1: the 4 waves stack along M (128-row panel, 32*TN columns).  WN = 2: a 2 x 2 wave grid
-// (64 rows x 64*TN columns), for products whose M fits 64-row panels with less padding.
+// (64 rows x 64*TN columns), for products whose M fits 64-row panels with less padding and, with
+// TN = 1 (64 x 64 tiles, tile64_inst.hip), for products too small to fill the chip with panels.
 template <int TN, int BK, bool A_KC, bool B_KC, bool MASK, bool ONES, int WN = 1>
 __global__ __launch_bounds__(THREADS, (MASK || WN > 1 || TN > 5) ? 2 : PSVAE_PANEL_OCC) void gemm_panel_kernel(GemmArgs g) {
     constexpr int WM = 4 / WN, BM = 32 * WM, BN = 32 * TN * WN;
@@ -94,8 +95,9 @@ __global__ __launch_bounds__(THREADS, (MASK || WN > 1 || TN > 5) ? 2 : PSVAE_PAN
     using LB = TileLoader<BN, BK, B_KC>;
     constexpr int A_FLOATS = BK * LA::STRIDE, B_FLOATS = BK * LB::STRIDE;
     constexpr int STAGE_FLOATS = A_FLOATS + B_FLOATS;
-    // two LDS stages where two workgroups of them still fit a CU's 160 KiB
-    constexpr int NBUF = (PSVAE_PANEL_NBUF == 2 && 2 * STAGE_FLOATS * 4 <= 76 * 1024) ? 2 : 1;
+    // two LDS stages where two workgroups of them still fit a CU's 160 KiB: always for the 64 x 64
+    // tiles of small products (one workgroup per CU at best, so nothing else hides a k-tile's loads)
+    constexpr int NBUF = ((PSVAE_PANEL_NBUF == 2 || (WN == 2 && TN == 1)) && 2 * STAGE_FLOATS * 4 <= 76 * 1024) ? 2 : 1;
     constexpr int EPI_STRIDE = 36, EPI_FLOATS = 4 * 32 * EPI_STRIDE;   // one 32x32 tile per wave
     constexpr int LDS_FLOATS = NBUF * STAGE_FLOATS > EPI_FLOATS ? NBUF * STAGE_FLOATS : EPI_FLOATS;
     __shared__ __align__(16) float smem[LDS_FLOATS];
@@ -145,7 +147,17 @@ __global__ __launch_bounds__(THREADS, (MASK || WN > 1 || TN > 5) ? 2 : PSVAE_PAN
     // the MFMAs of one k-tile from stage `buf`: operand registers for k-step s+1 are fetched from
     // LDS while the MFMAs of step s run; the scheduling barriers keep the compiler from sinking the
     // reads next to their use
+    // The 64 x 64 tiles sum each k-tile into a fresh accumulator and add it to the running total
+    // (two levels: chains of BK terms instead of K), which keeps their rounding error at that of a
+    // blocked CPU product; 16 vector adds per k-tile beside its 32 MFMAs.
+    constexpr bool TWO_LEVEL = (WN == 2 && TN == 1);
     auto multiply = [&](int buf, int k0) {
+        f32x16 total0;
+        if constexpr (TWO_LEVEL) {
+            total0 = acc[0];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
+        }
         const float *ar = a_rd + buf * STAGE_FLOATS, *br = b_rd + buf * STAGE_FLOATS;
         float a_cur = ar[0], b_cur[TN];
 #pragma unroll
@@ -173,6 +185,10 @@ __global__ __launch_bounds__(THREADS, (MASK || WN > 1 || TN > 5) ? 2 : PSVAE_PAN
 #pragma unroll
                 for (int j = 0; j < TN; ++j) b_cur[j] = b_nxt[j];
             }
+        }
+        if constexpr (TWO_LEVEL) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][r] += total0[r];
         }
     };
     if constexpr (NBUF == 1) {

@@ -162,6 +162,65 @@ def test_gemm_tall_narrow_products(M, N, K, lda, ldc):
         assert torch.equal(again, out)
 
 
+@pytest.mark.parametrize('M,N,K,ldc', [(716, 300, 300, 1200), (749, 656, 300, 656), (32, 200, 56, 200), (4096, 200, 200, 200),
+                                       (4096, 56, 400, 56), (288, 600, 100, 600), (100, 44, 68, 48), (64, 64, 64, 64),
+                                       (364, 300, 748, 300)])
+@pytest.mark.parametrize('a_kc,b_kc', [(True, True), (True, False), (False, True), (False, False)])
+def test_gemm_small_products_on_64x64_tiles(M, N, K, ldc, a_kc, b_kc):
+    """Products too small to fill the chip with 128-row panels (every layer of a batch of 32, the
+    per-molecule layers of a batch of 4096) run on 64 x 64 tiles: all four operand layouts, plain /
+    bias + ReLU / masked input with row sums / gated accumulate, into a row-strided output that
+    sits between guard zones - nothing outside the [M, N] view may change - and repeats are
+    bit-identical."""
+    from ps_vae_amd import hip
+    if (not a_kc and M % 4) or (not b_kc and N % 4):
+        pytest.skip('a 16-byte loader needs the contiguous extent to be a multiple of 4')
+    d = dev()
+    g = torch.Generator(device=d).manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn((M, K) if a_kc else (K, M), device=d, generator=g)
+    sa = (K, 1) if a_kc else (1, M)
+    Bt = torch.randn((N, K) if b_kc else (K, N), device=d, generator=g)
+    sb = (1, K) if b_kc else (N, 1)       # (stride along k, stride along n)
+    a64, b64 = A.as_strided((M, K), sa).double(), Bt.as_strided((K, N), sb).double()
+    bias = torch.randn(N, device=d, generator=g)
+    amask = torch.randn(A.shape, device=d, generator=g)
+    gate = torch.randn(M * ldc, device=d, generator=g)
+    pad = 1024
+
+    def run(**kw):
+        buf = torch.full((pad + M * ldc + pad,), 12345.0, device=d)
+        C = buf[pad:pad + M * ldc]
+        hip.gemm(M, N, K, A, sa[0], sa[1], Bt, sb[0], sb[1], C, ldc, **kw)
+        outside = torch.ones_like(buf, dtype=torch.bool)
+        outside[pad:pad + M * ldc].as_strided((M, N), (ldc, 1)).fill_(False)
+        assert bool((buf[outside] == 12345.0).all()), f'wrote outside the [M, N] view ({kw.keys()})'
+        return C.as_strided((M, N), (ldc, 1)).clone()
+    scale = (a64.abs() @ b64.abs())       # bounds the rounding of any summation order
+    want = a64 @ b64
+
+    def near(got, ref, what):
+        err = ((got.double() - ref).abs() / scale.clamp_min(1e-30)).max().item()
+        assert err < 2e-6, f'{what}: {err:.2e} of sum |a||b|'
+    plain = run()
+    near(plain, want, 'plain')
+    assert torch.equal(run(), plain) and torch.equal(run(), plain), 'repeats differ'
+    near(run(bias=bias, relu=True), torch.relu(want + bias.double()), 'bias + relu')
+    if not b_kc:                          # the row sums ride on a virtual ones column of an n-contiguous B
+        rs = torch.full((M,), 3.0, device=d)
+        am64 = a64 * (amask.as_strided((M, K), sa) > 0)
+        got = run(amask=amask, rowsum=rs)
+        err = ((got.double() - am64 @ b64).abs() / scale.clamp_min(1e-30)).max().item()
+        assert err < 2e-6, f'masked: {err:.2e}'
+        close(rs, am64.sum(1), rel=1e-5, what='row sums of the masked operand')
+    buf = torch.full((M * ldc,), 0.25, device=d)
+    hip.gemm(M, N, K, A, sa[0], sa[1], Bt, sb[0], sb[1], buf, ldc, cmask=gate, accumulate=True)
+    gated = (0.25 + want) * (gate.as_strided((M, N), (ldc, 1)) > 0)
+    near(buf.as_strided((M, N), (ldc, 1)), gated, 'gated +=')
+    if ldc > N:
+        rest = buf.as_strided((M, ldc - N), (ldc, 1), N)
+        assert bool((rest == 0.25).all()), 'columns beyond N were written'
+
+
 def test_gemm_tall_k_repeats_bit_for_bit():
     """The stacked conv-weight gradient of the benchmark (300 x 300 over 380 592 rows) forty times
     in a row: every result equals the first bit for bit.  The kernel's k-tiles reach LDS through

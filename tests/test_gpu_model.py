@@ -366,7 +366,7 @@ def test_loss_curve_follows_the_oracle_over_30_steps(tokenizer):
                 f'step {s} {k}: GPU {got[k]:.6f}, fp32 oracle {cpu32[k]:.6f}, float64 oracle {cpu64[k]:.6f}'
         curve.append(cpu64['loss'])
     assert curve[-1] < 0.9 * curve[0], (curve[0], curve[-1])      # the curve actually moves over these steps
-    for st in range(0, steps, 5):     # relative distance from the float64 curve, GPU / fp32 CPU oracle
+    for st in list(range(1, 5)) + list(range(0, steps, 5)):     # relative distance from the float64 curve, GPU / fp32 CPU oracle
         rows = [r for r in report if r[0] == st]
         print(st, ' '.join(f'{r[1]}:{r[2]:.1e}/{r[3]:.1e}' for r in rows))
     worst = max(report, key=lambda r: r[2])
