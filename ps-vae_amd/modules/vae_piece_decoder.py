@@ -113,10 +113,10 @@ class VAEPieceDecoder(nn.Module):
             # ever formed.  In training P ~ V, so the arithmetic is the same; over ALL candidate pairs
             # of generated molecules (pairs >> atoms) it is several times less.
             first = seq[0]
-            w = first.weight
-            w_nodes = torch.cat([w[:, :H], w[:, H:2 * H]], dim=0)      # [2F, H]: rows of Wa, then of Wb
+            w_a, w_b, w_z = ops.split_columns(first.weight, (H, H, L))
+            w_nodes = torch.cat([w_a, w_b], dim=0)                     # [2F, H]: rows of Wa, then of Wb
             huv = ops.linear(node_embedding, w_nodes)                  # [V, 2F]
-            hz = ops.linear(z_vecs, w[:, 2 * H:], first.bias)          # [B, F]
+            hz = ops.linear(z_vecs, w_z, first.bias)                   # [B, F]
             hid = ops.pair_combine(huv, hz, pairs, relu=True)
             hid = run_sequential(seq[2:-1], hid)
             weight, bias = ops.affine_merge(last.weight, last.bias, seq[-1].weight, seq[-1].bias)

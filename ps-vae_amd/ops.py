@@ -449,18 +449,44 @@ class _EmbedTrans(Function):
         return full[:ctx.rows], None
 
 
+class _SplitColumns(Function):
+    """Column blocks of a weight as views.  Autograd's own slicing would answer every block's gradient
+    with a zero-filled copy of the whole weight plus an add per block; here the gradient of the
+    weight is ONE concatenation of the blocks' gradients."""
+
+    @staticmethod
+    def forward(ctx, weight, *sizes):
+        ctx.sizes, ctx.rows = sizes, weight.shape[0]
+        out, col = [], 0
+        for d in sizes:
+            out.append(weight.narrow(1, col, d))
+            col += d
+        return tuple(out)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        ref = next(g for g in grads if g is not None)
+        parts = [g if g is not None else ref.new_zeros(ctx.rows, d) for g, d in zip(grads, ctx.sizes)]
+        return (torch.cat(parts, dim=1),) + (None,) * len(ctx.sizes)
+
+
+def split_columns(weight, sizes):
+    """weight[:, :s0], weight[:, s0:s0+s1], ... (the sizes must add up to the weight's width)."""
+    if sum(sizes) != weight.shape[1]:
+        raise ValueError(f'column blocks {tuple(sizes)} do not add up to the width {weight.shape[1]}')
+    return _SplitColumns.apply(weight, *sizes)
+
+
 def embed_trans(ids, weight, bias):
     """node_trans(embed_atom(ids)) without the embedded rows (src/modules/encoder.py:54 over
     src/modules/vae_piece_decoder.py:65-69): T = the tables times the matching column blocks of
     `weight` (three small products, bias folded into the atom rows, every atom having exactly
     one), then T[x] + T[n_atom + xp] + T[n_atom + n_piece + xq] per atom."""
-    parts, col = [], 0
-    for i, tab in enumerate(ids.tables):
-        d = tab.shape[1]
-        parts.append(linear(tab, weight[:, col:col + d], bias if i == 0 else None))
-        col += d
-    if col != weight.shape[1]:
-        raise ValueError(f'embedding widths sum to {col}, node_trans expects {weight.shape[1]}')
+    widths = [int(tab.shape[1]) for tab in ids.tables]
+    if sum(widths) != weight.shape[1]:
+        raise ValueError(f'embedding widths sum to {sum(widths)}, node_trans expects {weight.shape[1]}')
+    blocks = split_columns(weight, widths)
+    parts = [linear(tab, blk, bias if i == 0 else None) for i, (tab, blk) in enumerate(zip(ids.tables, blocks))]
     return _EmbedTrans.apply(torch.cat(parts, dim=0), ids)
 
 
