@@ -398,19 +398,29 @@ class EmbeddedIds:
         return embed_atom(self.x, self.xp, self.xq, *self.tables)
 
     def for_side_stream(self):
-        """The same ids with the tables passed through an identity node made HERE, on the current
-        stream.  A chain that then uses the result on another stream sends its table gradients
+        """The same ids with the block table passed through an identity node made HERE, on the current
+        stream.  A chain that then uses the result on another stream sends its table gradient
         back through that node, i.e. onto this stream, where the tables' other users and their
         gradient accumulators live (autograd joins the two streams at the node)."""
-        twin = EmbeddedIds(self.x, self.xp, self.xq, *(stream_handoff(t) for t in self.tables))
+        twin = EmbeddedIds(self.x, self.xp, self.xq, *self.tables)
+        twin._block = stream_handoff(self.block_table())
         if getattr(self, '_indicator', None) is not None:
             twin._indicator = self._indicator
         return twin
 
     def tensors(self):
         """Every device buffer this object owns (for record_stream on a second stream)."""
-        ind = getattr(self, '_indicator', None)
-        return (self.x, self.xp, self.xq) + ((ind,) if ind is not None else ())
+        extra = [t for t in (getattr(self, '_indicator', None), getattr(self, '_block', None)) if t is not None]
+        return (self.x, self.xp, self.xq) + tuple(extra)
+
+    def block_table(self):
+        """The three tables as ONE matrix [rows of all tables, D + 4]: table k sits in its own
+        column block (zeros elsewhere) and column D holds a one on the atom rows (the bias of
+        node_trans rides on it).  Built once per batch, on the stream current at the first call,
+        and shared by every encoder."""
+        if getattr(self, '_block', None) is None:
+            self._block = _BlockTable.apply(*self.tables)
+        return self._block
 
     def indicator(self):
         """[V, R4] f32, a one in the three key columns of every atom (R4 = table rows rounded
@@ -477,17 +487,48 @@ def split_columns(weight, sizes):
     return _SplitColumns.apply(weight, *sizes)
 
 
+class _BlockTable(Function):
+    @staticmethod
+    def forward(ctx, ea, ep, eq):
+        (na, da), (npc, dp), (nq, dq) = ea.shape, ep.shape, eq.shape
+        D = da + dp + dq
+        Z = ea.new_zeros(na + npc + nq, D + 4)
+        Z[:na, :da] = ea
+        Z[na:na + npc, da:da + dp] = ep
+        Z[na + npc:, da + dp:D] = eq
+        Z[:na, D] = 1.0
+        ctx.dims = (na, da, npc, dp, D)
+        return Z
+
+    @staticmethod
+    def backward(ctx, g):
+        na, da, npc, dp, D = ctx.dims
+        return g[:na, :da], g[na:na + npc, da:da + dp], g[na + npc:, da + dp:D]
+
+
+_ZERO_COLUMNS = {}
+
+
+def _zero_columns(rows, device):
+    key = (rows, device)
+    if key not in _ZERO_COLUMNS:
+        _ZERO_COLUMNS[key] = torch.zeros(rows, 3, dtype=torch.float32, device=device)
+    return _ZERO_COLUMNS[key]
+
+
 def embed_trans(ids, weight, bias):
     """node_trans(embed_atom(ids)) without the embedded rows (src/modules/encoder.py:54 over
-    src/modules/vae_piece_decoder.py:65-69): T = the tables times the matching column blocks of
-    `weight` (three small products, bias folded into the atom rows, every atom having exactly
-    one), then T[x] + T[n_atom + xp] + T[n_atom + n_piece + xq] per atom."""
-    widths = [int(tab.shape[1]) for tab in ids.tables]
-    if sum(widths) != weight.shape[1]:
-        raise ValueError(f'embedding widths sum to {sum(widths)}, node_trans expects {weight.shape[1]}')
-    blocks = split_columns(weight, widths)
-    parts = [linear(tab, blk, bias if i == 0 else None) for i, (tab, blk) in enumerate(zip(ids.tables, blocks))]
-    return _EmbedTrans.apply(torch.cat(parts, dim=0), ids)
+    src/modules/vae_piece_decoder.py:65-69): T = block table x [weight | bias | 0]^T - one small
+    product whose row r is table row r times the matching column block of `weight`, plus the bias
+    on the atom rows (every atom has exactly one) - then T[x] + T[n_atom + xp] +
+    T[n_atom + n_piece + xq] per atom."""
+    widths = sum(int(tab.shape[1]) for tab in ids.tables)
+    if widths != weight.shape[1]:
+        raise ValueError(f'embedding widths sum to {widths}, node_trans expects {weight.shape[1]}')
+    H = weight.shape[0]
+    b = bias[:, None] if bias is not None else _zero_columns(H, weight.device)[:, :1]
+    w_ext = torch.cat([weight, b, _zero_columns(H, weight.device)], dim=1)      # [H, D + 4]
+    return _EmbedTrans.apply(linear(ids.block_table(), w_ext), ids)
 
 
 # ------------------------------------------------------------------------ segment sum

@@ -302,15 +302,27 @@ def test_default_width_batch_256_against_oracle(tokenizer):
 
 def test_loss_curve_follows_the_oracle_over_30_steps(tokenizer):
     """Thirty optimisation steps (batch 32, default widths, KL weight stepping on from step 5)
-    on the GPU path — GPU collation, flat-gradient clip, fused Adam — beside the CPU oracle fed
-    the same molecules, uniforms and eps: every logged loss follows the oracle's curve.
+    on the GPU path - GPU collation, flat-gradient clip, fused Adam - beside the CPU oracle
+    trained in float64 on the same molecules, uniforms and eps.
 
-    Yardstick: the oracle trained in float64.  Rounding differences feed back through the
-    weights, so any two fp32 runs drift apart step by step: the fp32 CPU oracle itself leaves
-    the float64 curve at the same rate as the GPU path does (both reach ~1e-2 on the KL term,
-    the most sensitive one, by step 28, from ~1e-7 at step 1).  Every GPU loss must stay within
-    1e-5 relative of the float64 curve OR within ten times the largest distance the fp32 CPU
-    oracle has shown from it so far (any loss, any earlier step)."""
+    Two GPU models run the schedule.
+    * The LED one starts every step from the float64 oracle's weights and Adam moments
+      (rounded to fp32), so each of the thirty steps is compared where both sides still hold
+      the same weights: every loss and the clipped gradient norm within 1e-5 relative of
+      float64, and the update itself against Adam evaluated in float64 on the model's own
+      clipped gradient (weights within 2e-6 lr, both moments within 1e-6).
+    * The FREE one trains on its own.  Its curve can only be held loosely, because fp32
+      trajectories of this model separate in jumps: Adam's first steps move every weight by
+      about lr whatever the size of its gradient, and the decoder's message-passing weights
+      have gradient entries of the size of fp32 rounding, so rounding decides which way some
+      weights go.  The fp32 CPU oracle itself shows it - from initial weights one rounding step
+      (relative 2^-23) away from the given ones, two of five runs are 4e-5 / 6e-5 off the
+      float64 edge loss at step 3 and 1e-4 at step 5 while the others are still at 1e-6, and
+      which runs jump changes with the host's BLAS.  So the free model is held to 1e-5 at step
+      0 (same weights); afterwards the total, reconstruction, piece and edge losses to 1 % of the
+      float64 curve (observed: up to 3e-4) and the two small terms that amplify the drift most,
+      the property loss and the KL term (the fp32 CPU oracle's KL is 1e-2 off by step 25, the
+      GPU's up to 5e-2), to 20 %; and the curve must fall."""
     import copy
     from ps_vae_amd.data.collate import collate_packed
     from ps_vae_amd.data.packed import PackedMolecules
@@ -323,54 +335,107 @@ def test_loss_curve_follows_the_oracle_over_30_steps(tokenizer):
     ref64 = copy.deepcopy(ref).double()
     ref_opt = torch.optim.Adam(ref.parameters(), lr=cfg['lr'])
     ref64_opt = torch.optim.Adam(ref64.parameters(), lr=cfg['lr'])
-    model, hcfg = hip_model(tokenizer, state=ref.state_dict(), **sched)
-    (opt,), _ = model.configure_optimizers()      # optim.FlatAdam: exchange + clip + Adam on flat buffers
-    opt.max_norm = 10.0
+    led, _ = hip_model(tokenizer, state=ref.state_dict(), **sched)
+    free, _ = hip_model(tokenizer, state=ref.state_dict(), **sched)
+    (led_opt,), _ = led.configure_optimizers()      # optim.FlatAdam: exchange + clip + Adam on flat buffers
+    (free_opt,), _ = free.configure_optimizers()
+    led_opt.max_norm = free_opt.max_norm = 10.0
+    p64 = dict(ref64.named_parameters())
+    led_named = [(k, q) for k, q in led.named_parameters() if q.requires_grad]
+    assert [id(q) for _, q in led_named] == [id(q) for q in led_opt.sync.params]
+    offs, total = [], 0
+    for _, q in led_named:
+        offs.append(total)
+        total += (q.numel() + 3) // 4 * 4
+
+    def lead():
+        """weights, Adam moments and step count of the float64 oracle -> the led GPU model"""
+        with torch.no_grad():
+            for (k, q), o in zip(led_named, offs):
+                q.copy_(p64[k].detach().to(torch.float32))
+                st = ref64_opt.state.get(p64[k], {})
+                for name, flat in (('exp_avg', led_opt.exp_avg), ('exp_avg_sq', led_opt.exp_avg_sq)):
+                    slot = flat[o:o + q.numel()].view_as(q)
+                    if name in st:
+                        slot.copy_(st[name].to(torch.float32))
+                    else:
+                        slot.zero_()
+        led_opt.steps = led.global_step = ref64.global_step
+
     mols = synthetic_step1(steps * B, seed=77, shape='zinc')
     rng = np.random.default_rng(9)
     gen = torch.Generator().manual_seed(4)
     names = ['loss', 'pred', 'rec', 'piece', 'edge', 'kl']
-    report = []
-    curve = []
+    report, curve = [], []
+    worst_led, worst_update = (0.0, ''), (0.0, '')
     for s in range(steps):
         chunk = mols[s * B:(s + 1) * B]
         uniforms = rng.random(700 * B)
         eps = torch.randn(B, 56, generator=gen)
         ref_batch, used = collate_ref.collate(chunk, uniforms, piece_pad=tokenizer.pad_idx())
         tb = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in ref_batch.items()}
-        beta_ref = ref.cal_beta()
-        cpu32 = model_ref.train_step(ref, ref_opt, tb, eps)
         tb64 = {k: (v.double() if v.dtype == torch.float32 else v) for k, v in tb.items()}
-        cpu64 = model_ref.train_step(ref64, ref64_opt, tb64, eps.double())
-
         packed = PackedMolecules.from_step1(chunk)
         batch = collate_packed(packed.to_device(dev()), np.arange(B), uniforms=torch.from_numpy(uniforms).to(dev()),
                                atom_pad=tokenizer.atom_pad_idx(), piece_pad=tokenizer.pad_idx(),
                                reference_layout=False)
         assert batch.num_uniforms == used
-        opt.zero_grad()
-        pred_loss, (rec, piece, edge, kl) = model(batch, eps=eps.to(dev()))
-        assert abs(model.cal_beta() - beta_ref) < 1e-12
-        loss = model.weighted_loss(pred_loss, rec, kl)
-        loss.backward()
-        opt.step()
-        model.global_step += 1
-        got = dict(zip(names, (v.item() for v in (loss, pred_loss, rec, piece, edge, kl))))
+        lead()
+        before = {'p': led_opt.sync.flat_params.double(), 'm': led_opt.exp_avg.double(), 'v': led_opt.exp_avg_sq.double()}
+        beta_ref = ref64.cal_beta()
+        cpu32 = model_ref.train_step(ref, ref_opt, tb, eps)
+        # the float64 step, spelt out to keep the gradient norm and the moments it leaves
+        ref64_opt.zero_grad(set_to_none=True)
+        pl64, (rec64, piece64, edge64, kl64) = ref64(tb64, eps.double())
+        loss64 = ref64.weighted_loss(pl64, rec64, kl64)
+        loss64.backward()
+        norm64 = torch.nn.utils.clip_grad_norm_(ref64.parameters(), 10.0).item()
+        ref64_opt.step()
+        ref64.global_step += 1
+        cpu64 = dict(zip(names, (v.item() for v in (loss64, pl64, rec64, piece64, edge64, kl64))))
+
+        def gpu_step(model, opt):
+            opt.zero_grad()
+            pred_loss, (rec, piece, edge, kl) = model(batch, eps=eps.to(dev()))
+            assert abs(model.cal_beta() - beta_ref) < 1e-12
+            loss = model.weighted_loss(pred_loss, rec, kl)
+            loss.backward()
+            opt.step()
+            model.global_step += 1
+            return dict(zip(names, (v.item() for v in (loss, pred_loss, rec, piece, edge, kl))))
+        got_led, got_free = gpu_step(led, led_opt), gpu_step(free, free_opt)
         for k in names:
             scale = max(abs(cpu64[k]), 1e-12)
-            d_gpu, d_cpu = abs(got[k] - cpu64[k]) / scale, abs(cpu32[k] - cpu64[k]) / scale
-            report.append((s, k, d_gpu, d_cpu))
-        envelope = max(r[3] for r in report)
-        for _, k, d_gpu, _ in report[-len(names):]:
-            assert d_gpu <= max(1e-5, 10.0 * envelope), \
-                f'step {s} {k}: GPU {got[k]:.6f}, fp32 oracle {cpu32[k]:.6f}, float64 oracle {cpu64[k]:.6f}'
+            d_led = abs(got_led[k] - cpu64[k]) / scale
+            worst_led = max(worst_led, (d_led, f'step {s} {k}'))
+            assert d_led <= 1e-5, f'led model, step {s} {k}: GPU {got_led[k]:.7f}, float64 oracle {cpu64[k]:.7f}'
+            d_free, d_cpu = abs(got_free[k] - cpu64[k]) / scale, abs(cpu32[k] - cpu64[k]) / scale
+            report.append((s, k, d_free, d_cpu))
+            assert d_free <= (1e-5 if s == 0 else (1e-2 if k in ('loss', 'rec', 'piece', 'edge') else 2e-1)), \
+                f'free model, step {s} {k}: GPU {got_free[k]:.6f}, fp32 oracle {cpu32[k]:.6f}, float64 oracle {cpu64[k]:.6f}'
+        assert abs(float(led_opt.grad_norm) - norm64) <= 1e-5 * norm64, (s, float(led_opt.grad_norm), norm64)
+        # the update itself: Adam in float64 from the led model's OWN clipped gradient (left in the
+        # flat buffer) and the moments / weights it started the step with
+        t, lr = ref64.global_step, cfg['lr']
+        g = led_opt.sync.flat.double()
+        m = 0.9 * before['m'] + 0.1 * g
+        v = 0.999 * before['v'] + 0.001 * g * g
+        want_p = before['p'] - (lr / (1 - 0.9 ** t)) * m / ((v / (1 - 0.999 ** t)).sqrt() + 1e-8)
+        err = ((led_opt.sync.flat_params.double() - want_p).abs() - 1e-7 * want_p.abs()).max().item()
+        worst_update = max(worst_update, (err / lr, f'step {s}'))
+        assert err <= 2e-6 * lr, f'led model, weights after step {s}: {err / lr:.2e} of lr off Adam in float64'
+        m_size = 0.9 * before['m'].abs() + 0.1 * g.abs()      # (the two terms of m may cancel; those of v cannot)
+        assert bool(((led_opt.exp_avg.double() - m).abs() <= 1e-6 * m_size + 1e-30).all()), f'first moment after step {s}'
+        assert bool(((led_opt.exp_avg_sq.double() - v).abs() <= 1e-6 * v + 1e-30).all()), f'second moment after step {s}'
         curve.append(cpu64['loss'])
     assert curve[-1] < 0.9 * curve[0], (curve[0], curve[-1])      # the curve actually moves over these steps
-    for st in list(range(1, 5)) + list(range(0, steps, 5)):     # relative distance from the float64 curve, GPU / fp32 CPU oracle
+    print(f'led model: largest loss distance from float64 {worst_led[0]:.2e} ({worst_led[1]}), '
+          f'largest distance of an update from Adam in float64 {worst_update[0]:.2e} lr ({worst_update[1]})')
+    for st in list(range(0, 5)) + list(range(5, steps, 5)):     # free model / fp32 CPU oracle: distance from the float64 curve
         rows = [r for r in report if r[0] == st]
         print(st, ' '.join(f'{r[1]}:{r[2]:.1e}/{r[3]:.1e}' for r in rows))
     worst = max(report, key=lambda r: r[2])
-    print(f'largest GPU deviation from the float64 curve: step {worst[0]} {worst[1]} {worst[2]:.2e} '
+    print(f'free model: largest deviation from the float64 curve: step {worst[0]} {worst[1]} {worst[2]:.2e} '
           f'(fp32 CPU oracle there: {worst[3]:.2e}); loss {curve[0]:.4f} -> {curve[-1]:.4f}')
 
 
