@@ -333,14 +333,16 @@ int psvae_link_ce_bwd_input(int P, int F, int C, const float *dlogits, const flo
  * (nn.CrossEntropyLoss(ignore_index=pad): src/modules/vae_piece_decoder.py:53,113-114):
  * logits [R,V] rows of stride ld, gold [R]; over the rows with gold != ignore_index
  *     loss[0] = mean( logsumexp(logits[r]) - logits[r][gold[r]] ),  loss[1] = 1 / #rows
- * (no such row: NaN, as torch's mean over nothing); dlogits [R,V] (dense) = softmax - onehot, zero
- * rows where ignored: times g_loss * loss[1] it is the gradient; counts[0] = #rows,
+ * (no such row: NaN, as torch's mean over nothing); dlogits [R,V] (rows of stride ldd >= V) =
+ * softmax - onehot, zero rows where ignored, and zeros in the columns V..ldd-1 of every row (a
+ * vocabulary padded to a multiple of 4 so that the products on either side take the 16-byte
+ * loaders): times g_loss * loss[1] it is the gradient; counts[0] = #rows,
  * counts[1] = #{r : first argmax == gold[r]} (src/modules/vae_piece_decoder.py:120-122).
- * V <= 1024.  Sums run in a fixed order.
+ * V, ldd <= 1024.  Sums run in a fixed order.
  * ---------------------------------------------------------------------------------- */
 size_t psvae_token_ce_workspace_bytes(int R);
 int psvae_token_ce_fwd(int R, int V, const float *logits, int64_t ld, const int32_t *gold, int ignore_index,
-                       float *dlogits, float *loss, int32_t *counts,
+                       float *dlogits, int64_t ldd, float *loss, int32_t *counts,
                        void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------

@@ -20,7 +20,8 @@ struct CePartial {
 template <int PER_LANE>
 __global__ __launch_bounds__(CE_THREADS) void token_ce_kernel(int R, int V, const float *__restrict__ x, long long ld,
                                                               const int *__restrict__ gold, int ignore,
-                                                              float *__restrict__ dx, CePartial *__restrict__ part) {
+                                                              float *__restrict__ dx, long long ldd,
+                                                              CePartial *__restrict__ part) {
     __shared__ CePartial sh[CE_WAVES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float loss = 0.f;
@@ -54,11 +55,14 @@ __global__ __launch_bounds__(CE_THREADS) void token_ce_kernel(int R, int V, cons
         const int g = gold[r];
         const bool live = g != ignore;
         const float inv = 1.f / sum;
-        float *drow = dx + r * (long long)V;
+        float *drow = dx + r * ldd;
 #pragma unroll
         for (int i = 0; i < PER_LANE; ++i) {
             const int c = lane + 64 * i;
-            if (c < V) drow[c] = live ? v[i] * inv - (c == g ? 1.f : 0.f) : 0.f;
+            if (c < V)
+                drow[c] = live ? v[i] * inv - (c == g ? 1.f : 0.f) : 0.f;
+            else if (c < ldd)
+                drow[c] = 0.f;   // padding columns of a vocabulary rounded up for the products that follow
         }
         if (live) {
             const float xg = (g >= 0 && g < V) ? row[g] : 0.f;   // (a label outside the vocabulary is the caller's error)
@@ -113,22 +117,24 @@ int ce_blocks(int R) {
 extern "C" size_t psvae_token_ce_workspace_bytes(int R) { return (size_t)ce_blocks(R > 0 ? R : 0) * sizeof(CePartial); }
 
 extern "C" int psvae_token_ce_fwd(int R, int V, const float *logits, int64_t ld, const int32_t *gold, int ignore_index,
-                                  float *dlogits, float *loss, int32_t *counts, void *workspace, size_t workspace_bytes,
-                                  void *stream) {
+                                  float *dlogits, int64_t ldd, float *loss, int32_t *counts, void *workspace,
+                                  size_t workspace_bytes, void *stream) {
     PSVAE_REQUIRE(R >= 0 && V >= 1, PSVAE_EINVAL, "psvae_token_ce_fwd: bad shape %d x %d", R, V);
     PSVAE_REQUIRE(V <= 64 * CE_MAX_PER_LANE, PSVAE_ETOOLARGE, "psvae_token_ce_fwd: vocabulary %d > %d", V, 64 * CE_MAX_PER_LANE);
     PSVAE_REQUIRE(loss != nullptr && counts != nullptr, PSVAE_EINVAL, "psvae_token_ce_fwd: null output");
-    PSVAE_REQUIRE(R == 0 || (logits != nullptr && gold != nullptr && dlogits != nullptr && ld >= V), PSVAE_EINVAL,
-                  "psvae_token_ce_fwd: null operand or ld < V");
+    PSVAE_REQUIRE(R == 0 || (logits != nullptr && gold != nullptr && dlogits != nullptr && ld >= V && ldd >= V), PSVAE_EINVAL,
+                  "psvae_token_ce_fwd: null operand or a row stride below V");
+    PSVAE_REQUIRE(ldd <= 64 * CE_MAX_PER_LANE, PSVAE_ETOOLARGE, "psvae_token_ce_fwd: dlogits row stride %lld > %d",
+                  (long long)ldd, 64 * CE_MAX_PER_LANE);
     const int blocks = ce_blocks(R);
     PSVAE_REQUIRE(workspace != nullptr && workspace_bytes >= (size_t)blocks * sizeof(CePartial), PSVAE_EWORKSPACE,
                   "psvae_token_ce_fwd: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     CePartial *part = (CePartial *)workspace;
-    const int per_lane = psvae_cdiv(V, 64);
+    const int per_lane = psvae_cdiv(R > 0 && ldd > V ? (int)ldd : V, 64);
 #define PSVAE_CE(N) \
     hipLaunchKernelGGL((token_ce_kernel<N>), dim3(blocks), dim3(CE_THREADS), 0, s, R, V, logits, (long long)ld, gold, \
-                       ignore_index, dlogits, part)
+                       ignore_index, dlogits, (long long)ldd, part)
     if (per_lane <= 1) PSVAE_CE(1);
     else if (per_lane <= 2) PSVAE_CE(2);
     else if (per_lane <= 5) PSVAE_CE(5);

@@ -187,15 +187,18 @@ void rsample_kl_bwd(const Tensor &mean, const Tensor &lv_pre, const Tensor &eps,
                                const_cast<float *>(f32c(g_lv_pre, fn)), cur_stream(g_mean)), fn);
 }
 
-void token_ce_fwd(const Tensor &logits, const Tensor &gold, int64_t ignore_index, Tensor dlogits, Tensor loss, Tensor counts) {
+void token_ce_fwd(const Tensor &logits, const Tensor &gold, int64_t ignore_index, int64_t n_classes, Tensor dlogits, Tensor loss,
+                  Tensor counts) {
     const char *fn = "psvae_token_ce_fwd";
-    const int R = (int)logits.size(0), V = (int)logits.size(1);
+    const int R = (int)logits.size(0), V = (int)n_classes;
+    TORCH_CHECK(V >= 1 && V <= logits.size(1) && dlogits.size(0) == R && dlogits.size(1) >= V, fn, ": n_classes / dlogits shape");
     void *s = cur_stream(loss);
     const size_t nbytes = psvae_token_ce_workspace_bytes(R);
     Tensor hold = workspace(nbytes, loss, s);
     TORCH_CHECK(counts.is_cuda() && counts.scalar_type() == at::kInt, fn, ": counts must be an int32 GPU tensor");
     check(psvae_token_ce_fwd(R, V, R ? f32(logits, fn) : nullptr, R ? row_stride(logits, fn) : V, R ? i32(gold, fn) : nullptr,
-                             (int)ignore_index, R ? const_cast<float *>(f32c(dlogits, fn)) : nullptr, f32_mut(loss, fn),
+                             (int)ignore_index, R ? const_cast<float *>(f32c(dlogits, fn)) : nullptr,
+                             R ? std::max<int64_t>(row_stride(dlogits, fn), dlogits.size(1)) : V, f32_mut(loss, fn),
                              counts.data_ptr<int32_t>(), hold.data_ptr(), nbytes, s), fn);
 }
 
@@ -298,7 +301,8 @@ TORCH_LIBRARY(psvae, m) {
     m.def("rsample_kl_fwd(Tensor mean, Tensor lv_pre, Tensor eps, Tensor(a!) z, Tensor(b!) kl) -> ()", &rsample_kl_fwd);
     m.def("rsample_kl_bwd(Tensor mean, Tensor lv_pre, Tensor eps, Tensor? g_z, Tensor? g_kl, Tensor(a!) g_mean, "
           "Tensor(b!) g_lv_pre) -> ()", &rsample_kl_bwd);
-    m.def("token_ce_fwd(Tensor logits, Tensor gold, int ignore_index, Tensor(a!) dlogits, Tensor(b!) loss, Tensor(c!) counts) -> ()",
+    m.def("token_ce_fwd(Tensor logits, Tensor gold, int ignore_index, int n_classes, Tensor(a!) dlogits, Tensor(b!) loss, "
+          "Tensor(c!) counts) -> ()",
           &token_ce_fwd);
     m.def("embed_trans_fwd(Tensor x, Tensor xp, Tensor xq, int n_atom, int n_piece, int n_pos, Tensor T, Tensor(a!) out) -> ()",
           &embed_trans_fwd);

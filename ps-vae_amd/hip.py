@@ -65,7 +65,7 @@ _SIGNATURES = {
     'psvae_pair_combine_bwd': (_c_int, [_c_int, _c_int, _p, _c_int, _p, _c_int, _c_int, _p, _p, _p, _p, _p, _p, _c_int, _p,
                                         _c_int, _p]),
     'psvae_token_ce_workspace_bytes': (_c_size, [_c_int]),
-    'psvae_token_ce_fwd': (_c_int, [_c_int, _c_int, _p, _c_i64, _p, _c_int, _p, _p, _p, _p, _c_size, _p]),
+    'psvae_token_ce_fwd': (_c_int, [_c_int, _c_int, _p, _c_i64, _p, _c_int, _p, _c_i64, _p, _p, _p, _c_size, _p]),
     'psvae_link_infer': (_c_int, [_c_int, _c_int, _p, _c_f32, _c_int, _p, _p, _p, _p]),
     'psvae_embed_trans_fwd': (_c_int, [_c_int, _c_int, _p, _p, _p, _c_int, _c_int, _c_int, _p, _p, _c_int, _p]),
     'psvae_clip_adam_workspace_bytes': (_c_size, [_c_ll]),
@@ -451,10 +451,11 @@ def link_ce_bwd_input(dlogits, W, g_loss, g_hid):
     ops().link_ce_bwd_input(dlogits, W, g_loss, g_hid)
 
 
-def token_ce_fwd(logits, gold, ignore_index, dlogits, loss, counts):
-    """logits [R,V] (rows of any stride), gold int32 [R] -> dlogits [R,V], loss f32[2], counts i32[2]."""
+def token_ce_fwd(logits, gold, ignore_index, n_classes, dlogits, loss, counts):
+    """logits [R, >= n_classes] (rows of any stride), gold int32 [R] -> dlogits (same width as its
+    rows are wide: columns from n_classes on are zeroed), loss f32[2], counts i32[2]."""
     _count()
-    ops().token_ce_fwd(logits, gold, int(ignore_index), dlogits, loss, counts)
+    ops().token_ce_fwd(logits, gold, int(ignore_index), int(n_classes), dlogits, loss, counts)
 
 
 def link_infer(logits, add_edge_th, none_bond, conf, etype, keep):

@@ -18,6 +18,15 @@ from .encoder import Encoder
 
 
 _SIDE_STREAMS = {}   # one extra stream per device, shared by every decoder instance
+_ZERO_ROWS = {}
+
+
+def _zero_rows(rows, width, device):
+    """A cached [rows, width] block of zeros (padding rows of a weight; never written)."""
+    key = (rows, width, device)
+    if key not in _ZERO_ROWS:
+        _ZERO_ROWS[key] = torch.zeros(rows, width, dtype=torch.float32, device=device)
+    return _ZERO_ROWS[key]
 
 
 class VAEPieceDecoder(nn.Module):
@@ -69,12 +78,15 @@ class VAEPieceDecoder(nn.Module):
                              self.piece_embedding.weight, self.pos_embedding.weight)
         return out.view(*shape, out.shape[-1])
 
-    def piece_logits(self, z_vecs, pieces, piece_table=None, time_major=False):
+    def piece_logits(self, z_vecs, pieces, piece_table=None, time_major=False, pad_vocab=False):
         """:81-90 — teacher-forced GRU over the piece sequence, initial state from z.
         piece_table: self.piece_embedding.weight as the caller wants it seen by autograd (the
         two-stream schedule hands it over from the main stream).  Returns [B, S-1, vocab]; with
         time_major=True the same logits as the GRU path produces them, [S-1, B, vocab] (no
-        transposition: a loss that is a mean over tokens does not care about their order)."""
+        transposition: a loss that is a mean over tokens does not care about their order).
+        pad_vocab (time-major GRU path only): the vocabulary layer gets zero rows up to a multiple of
+        four classes, so [S-1, B, vocab rounded up]: the three products around the logits then take
+        the 16-byte loaders (302 classes do not); the loss kernel is told the real class count."""
         rnn = self.rnn
         init_hidden = run_linear(self.latent_to_rnn_hidden, z_vecs)
         if rnn.num_layers == 1 and not rnn.bidirectional and rnn.bias:
@@ -83,7 +95,13 @@ class VAEPieceDecoder(nn.Module):
             table = self.piece_embedding.weight if piece_table is None else piece_table
             emb = ops.embedding(ids, table) if table.shape[1] % 4 == 0 else self.piece_embedding(ids.long())
             hs = ops.gru(emb, init_hidden, rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.bias_ih_l0, rnn.bias_hh_l0)
-            out = run_linear(self.to_vocab, hs)
+            pad = (-self.to_vocab.out_features) % 4 if (pad_vocab and time_major and self.to_vocab.bias is not None) else 0
+            if pad:
+                zeros = _zero_rows(pad, self.to_vocab.in_features, hs.device)
+                out = ops.linear(hs, torch.cat([self.to_vocab.weight, zeros], dim=0),
+                                 torch.cat([self.to_vocab.bias, zeros[:, 0]], dim=0))
+            else:
+                out = run_linear(self.to_vocab, hs)
             return out if time_major else out.transpose(0, 1)
         output, _ = rnn(self.piece_embedding(pieces)[:, :-1], init_hidden.unsqueeze(0))
         out = run_linear(self.to_vocab, output)
@@ -93,9 +111,9 @@ class VAEPieceDecoder(nn.Module):
         """:81-90 + :113-114 (+ the counts behind :120-122): the piece language model's logits and
         their cross-entropy against pieces[:, 1:] with <pad> ignored, in one kernel on the
         time-major logits.  Returns (loss, counts int32 [non-pad tokens, correct argmax])."""
-        logits = self.piece_logits(z_vecs, pieces, piece_table, time_major=True)
+        logits = self.piece_logits(z_vecs, pieces, piece_table, time_major=True, pad_vocab=True)
         gold = pieces[:, 1:].t().contiguous().to(torch.int32)
-        return ops.token_ce(logits, gold, self.piece_loss.ignore_index)
+        return ops.token_ce(logits, gold, self.piece_loss.ignore_index, n_classes=self.to_vocab.out_features)
 
     def link_logits(self, node_embedding, z_vecs, pairs, golden=None):
         """:99-110 (+ :115 when `golden` is given).  node_embedding [V,H] in the node ids the

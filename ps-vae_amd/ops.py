@@ -800,14 +800,14 @@ def link_ce(hid, weight, bias, golden):
 # ------------------------------------------------------------------------ token loss with an ignored label
 class _TokenCe(Function):
     @staticmethod
-    def forward(ctx, logits, gold, ignore_index):
+    def forward(ctx, logits, gold, ignore_index, n_classes):
         x = _rows2d(logits)
-        R, V = x.shape
+        R, width = x.shape
         dev = x.device
-        dlogits = torch.empty(R, V, dtype=torch.float32, device=dev)
+        dlogits = torch.empty(R, width, dtype=torch.float32, device=dev)
         loss = torch.empty(2, dtype=torch.float32, device=dev)
         counts = torch.empty(2, dtype=torch.int32, device=dev)
-        hip.token_ce_fwd(x, gold, ignore_index, dlogits, loss, counts)
+        hip.token_ce_fwd(x, gold, ignore_index, n_classes, dlogits, loss, counts)
         ctx.save_for_backward(dlogits, loss)
         ctx.shape = logits.shape
         ctx.mark_non_differentiable(counts)
@@ -817,12 +817,14 @@ class _TokenCe(Function):
     def backward(ctx, g_loss, _g_counts):
         dlogits, loss = ctx.saved_tensors
         # the saved rows are softmax - onehot: times g_loss / #tokens they are the gradient
-        return (dlogits * (g_loss.float() * loss[1])).view(ctx.shape), None, None
+        return (dlogits * (g_loss.float() * loss[1])).view(ctx.shape), None, None, None
 
 
-def token_ce(logits, gold, ignore_index):
+def token_ce(logits, gold, ignore_index, n_classes=None):
     """Mean cross-entropy over the rows whose label is not `ignore_index`
     (nn.CrossEntropyLoss(ignore_index=...)).  logits [..., V] f32, gold int32 [...] (same leading
-    shape, flattened).  Returns (loss, counts) with counts = int32 [#rows counted, #rows whose
-    argmax is the label]."""
-    return _TokenCe.apply(logits.reshape(-1, logits.shape[-1]), gold.reshape(-1), ignore_index)
+    shape, flattened).  n_classes < V: only the first n_classes columns are classes, the rest is
+    padding (ignored, zero gradient).  Returns (loss, counts) with counts = int32 [#rows counted,
+    #rows whose argmax is the label]."""
+    width = logits.shape[-1]
+    return _TokenCe.apply(logits.reshape(-1, width), gold.reshape(-1), ignore_index, width if n_classes is None else n_classes)

@@ -898,6 +898,28 @@ def test_token_ce_against_torch(R, V, ld):
     assert counts.tolist() == [int(live.sum()), hits]
 
 
+def test_token_ce_with_padded_vocabulary():
+    """Logits whose last columns are padding (302 classes in rows of 304): loss, counts and the
+    gradient of the class columns equal the unpadded call's, the padding columns get zero gradient
+    whatever they hold."""
+    from ps_vae_amd import ops as hip_ops
+    d = dev()
+    g = torch.Generator().manual_seed(5)
+    R, V, W = 1000, 302, 304
+    x = (torch.randn(R, W, generator=g) * 3).to(d)
+    x[:, V:] = 50.0                      # would win every argmax and dominate every softmax if it were read
+    gold = torch.randint(0, V, (R,), generator=g).to(d).to(torch.int32)
+    gold[::7] = V - 1
+    a = x.clone().requires_grad_(True)
+    b = x[:, :V].clone().requires_grad_(True)
+    la, ca = hip_ops.token_ce(a, gold, V - 1, n_classes=V)
+    lb, cb = hip_ops.token_ce(b, gold, V - 1)
+    assert la.item() == lb.item() and ca.tolist() == cb.tolist()
+    la.backward()
+    lb.backward()
+    assert torch.equal(a.grad[:, :V], b.grad) and not bool(a.grad[:, V:].any())
+
+
 def test_token_ce_all_rows_ignored_is_nan():
     from ps_vae_amd import ops as hip_ops
     d = dev()
