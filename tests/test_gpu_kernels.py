@@ -221,6 +221,72 @@ def test_gemm_small_products_on_64x64_tiles(M, N, K, ldc, a_kc, b_kc):
         assert bool((rest == 0.25).all()), 'columns beyond N were written'
 
 
+def test_gemm_random_shapes_and_forms():
+    """Eighty seeded random products across the dispatch boundaries (64 x 64 tiles / 128-row panels /
+    2 x 2 wave grid / scalar-load kernel, automatic and explicit K splits): random operand layouts,
+    row-strided outputs, bias / ReLU / masked operand / row sums / gate / accumulate in random
+    combination, every result against float64 relative to sum |a||b| and the memory around the
+    [M, N] view untouched."""
+    from ps_vae_amd import hip
+    d = dev()
+    rng = np.random.default_rng(2024)
+    g = torch.Generator(device=d).manual_seed(11)
+    for case in range(80):
+        M = int(rng.choice([1, 5, 31, 32, 33, 64, 100, 128, 300, 364, 513, 749, 1500, 4096, 9000]))
+        N = int(rng.choice([1, 2, 4, 44, 56, 64, 100, 200, 300, 302, 328, 400, 656]))
+        K = int(rng.choice([1, 2, 11, 32, 50, 64, 100, 204, 300, 328, 656, 1200, 3000]))
+        a_kc, b_kc = bool(rng.integers(2)), bool(rng.integers(2))
+        ldc = N + int(rng.choice([0, 0, 4, 900]))
+        lda = (K if a_kc else M) + int(rng.choice([0, 0, 4, 12]))
+        ldb = (K if b_kc else N) + int(rng.choice([0, 0, 8]))
+        A = torch.randn((M, lda) if a_kc else (K, lda), device=d, generator=g)
+        Bt = torch.randn((N, ldb) if b_kc else (K, ldb), device=d, generator=g)
+        sa = (lda, 1) if a_kc else (1, lda)
+        sb = (1, ldb) if b_kc else (ldb, 1)
+        kw = {}
+        if rng.integers(2):
+            kw['bias'] = torch.randn(N, device=d, generator=g)
+        if rng.integers(3) == 0:
+            kw['relu'] = True
+        if rng.integers(3) == 0:
+            kw['amask'] = torch.randn(A.shape, device=d, generator=g)
+        if rng.integers(3) == 0 and 'bias' not in kw and 'relu' not in kw:
+            kw['rowsum'] = torch.full((M,), 2.0, device=d)
+        if rng.integers(3) == 0:
+            kw['cmask'] = torch.randn(M * ldc, device=d, generator=g)
+        acc = bool(rng.integers(4) == 0)
+        kw['split_k'] = int(rng.choice([0, 0, 0, 1, 2, 3, 7]))
+        pad = 512
+        buf = torch.full((pad + M * ldc + pad,), 0.75, device=d)
+        C = buf[pad:pad + M * ldc]
+        a64 = A.as_strided((M, K), sa).double()
+        if 'amask' in kw:
+            a64 = a64 * (kw['amask'].as_strided((M, K), sa) > 0)
+        b64 = Bt.as_strided((K, N), sb).double()
+        want = a64 @ b64
+        if 'bias' in kw:
+            want = want + kw['bias'].double()
+        if kw.get('relu'):
+            want = want.clamp_min(0)
+        if acc:
+            want = want + 0.75
+        if 'cmask' in kw:
+            want = want * (kw['cmask'].as_strided((M, N), (ldc, 1)) > 0)
+        hip.gemm(M, N, K, A, sa[0], sa[1], Bt, sb[0], sb[1], C, ldc, accumulate=acc, **kw)
+        what = f'case {case}: M={M} N={N} K={K} a_kc={a_kc} b_kc={b_kc} lda={lda} ldb={ldb} ldc={ldc} acc={acc} ' \
+               f'{ {k: (v if not torch.is_tensor(v) else "yes") for k, v in kw.items()} }'
+        scale = (a64.abs() @ b64.abs()) + 1.0
+        err = ((C.as_strided((M, N), (ldc, 1)).double() - want).abs() / scale).max().item()
+        assert err < 3e-6, f'{what}: {err:.2e} of sum |a||b| + 1'
+        outside = torch.ones_like(buf, dtype=torch.bool)
+        outside[pad:pad + M * ldc].as_strided((M, N), (ldc, 1)).fill_(False)
+        assert bool((buf[outside] == 0.75).all()), f'{what}: wrote outside the [M, N] view'
+        if 'rowsum' in kw:
+            want_rs = a64.sum(1) + (2.0 if acc else 0.0)
+            rs_err = ((kw['rowsum'].double() - want_rs).abs() / (a64.abs().sum(1) + 1.0)).max().item()
+            assert rs_err < 3e-6, f'{what}: row sums {rs_err:.2e}'
+
+
 def test_gemm_tall_k_repeats_bit_for_bit():
     """The stacked conv-weight gradient of the benchmark (300 x 300 over 380 592 rows) forty times
     in a row: every result equals the first bit for bit.  The kernel's k-tiles reach LDS through
