@@ -241,17 +241,20 @@ class _GineEncoder(Function):
         only_last = ctx.only_last      # then g_all is the gradient of the last iterate alone, [V,H]
         if g_all.dtype != torch.float32:
             g_all = g_all.float()
-        if not only_last and not g_all.is_contiguous():
+        if not g_all.is_contiguous():
             g_all = g_all.contiguous()
         f32 = dict(dtype=torch.float32, device=dev)
-        gx = torch.empty(t, V, H, **f32)      # dL/d x_i (output of layer i), stacked for the dW2 product
+        # dL/d x_i (output of layer i) for i < t-1, stacked for the dW2 product; the gradient of the
+        # last iterate is read where it arrives (a [V,H] block of g_all): no copy into the stack
+        last = g_all if only_last else g_all[:, (t - 1) * H:]
+        gx = torch.empty(max(t - 1, 1), V, H, **f32)
         gh = torch.empty(t, V, H, **f32)      # dL/d (pre-activation of h_i): gated as it is produced
         ga = torch.empty(V, H, **f32)
         g_x0 = torch.empty(V, H, **f32)
         g_table = torch.empty_like(table)
-        gx[t - 1].copy_(g_all if only_last else g_all[:, (t - 1) * H:])
         for i in range(t - 1, -1, -1):
-            hip.gemm(V, H, H, gx[i], H, 1, w2, H, 1, gh[i], H, cmask=h[i])      # through the last Linear + ReLU
+            g_i = last if i == t - 1 else gx[i]
+            hip.gemm(V, H, H, g_i, _ld(g_i), 1, w2, H, 1, gh[i], H, cmask=h[i])   # through the last Linear + ReLU
             hip.gemm(V, H, H, gh[i], H, 1, w1, H, 1, ga, H)                     # through the first Linear
             first = i == t - 1
             if i > 0:
@@ -265,8 +268,11 @@ class _GineEncoder(Function):
         gw2, gb2 = torch.empty_like(w2), torch.empty(H, **f32)
         gw1, gb1 = torch.empty_like(w1), torch.empty(H, **f32)
         TV = t * V
-        gx2, gh2, h2, a2 = gx.view(TV, H), gh.view(TV, H), h.view(TV, H), a.view(TV, H)
-        hip.gemm(H, H, TV, gx2, 1, H, h2, H, 1, gw2, H, split_k=0, rowsum=gb2)
+        gh2, a2 = gh.view(TV, H), a.view(TV, H)
+        if t > 1:     # layers 0 .. t-2 as one product over their stacked rows, then the last layer's block on top
+            SV = (t - 1) * V
+            hip.gemm(H, H, SV, gx.view(-1, H)[:SV], 1, H, h.view(TV, H)[:SV], H, 1, gw2, H, split_k=0, rowsum=gb2)
+        hip.gemm(H, H, V, last, 1, _ld(last), h[t - 1], H, 1, gw2, H, split_k=0, rowsum=gb2, accumulate=t > 1)
         hip.gemm(H, H, TV, gh2, 1, H, a2, H, 1, gw1, H, split_k=0, rowsum=gb1)
         if w0 is None:
             return g_x0, None, None, g_table, gw1, gb1, gw2, gb2, None, None, None
