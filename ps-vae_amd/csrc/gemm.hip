@@ -226,7 +226,7 @@ int resolve_split(int M, int N, int K, int split_k) {
 // four 64-deep k-tiles per workgroup and stops at one workgroup per CU (never more splits than
 // resolve_split grants: the workspace is sized from that).
 #ifndef PSVAE_TILE64_BELOW
-#define PSVAE_TILE64_BELOW 128   // (the -D override exists for A/B builds only)
+#define PSVAE_TILE64_BELOW 256   // (the -D override exists for A/B builds only)
 #endif
 constexpr int TILE64_BELOW_BLOCKS = PSVAE_TILE64_BELOW;
 int tile64_split(int M, int n_ext, int K) {
