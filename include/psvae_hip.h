@@ -190,7 +190,10 @@ int psvae_gine_aggregate_bwd_noalloc(int V, int H, int C, const float *x, int ld
  * accumulate != 0 adds to C (and rowsum).  split_k > 1 reduces partial products through
  * `workspace` in a fixed order; split_k == 0 lets the library choose.
  * Operands with unit stride along one axis, 16-byte aligned bases and major strides that
- * are multiples of 4 take the fast kernel; anything else a slower generic one.
+ * are multiples of 4 take the fast kernels (128-row panels; 64 x 64 tiles, whose 64-deep k-tiles
+ * are summed in two levels, when the panels would give fewer than 256 workgroups; a kernel of its
+ * own for weight gradients over more than 16 384 rows); anything else a slower generic one.
+ * Which kernel runs depends on the shapes and strides only: equal calls give equal bits.
  * ---------------------------------------------------------------------------------- */
 size_t psvae_gemm_f32_workspace_bytes(int M, int N, int K, int split_k);
 int psvae_gemm_f32(int M, int N, int K,
