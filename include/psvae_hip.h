@@ -203,6 +203,24 @@ int psvae_gemm_f32(int M, int N, int K,
                    int act, int accumulate,
                    int split_k, void *workspace, size_t workspace_bytes, void *stream);
 
+/* The same product with the ReLU decisions carried as BITS instead of a full-width gate (no
+ * amask / cmask / rowsum / accumulate / K split): one 64-bit lane mask per 32 x 32 tile of C, row
+ * group i (0..3) and component (0..3), at index ((row / 32) * ceil(N / 32) + col / 32) * 16 + 4 i +
+ * component; bit l of it belongs to row 32 * (row / 32) + (l >> 3) + 8 i, column
+ * 32 * (col / 32) + 4 * (l & 7) + component.  psvae_gemm_f32_bits_words(M, N) 64-bit words.
+ * relu_bits (optional): written, bit = (C[m][n] > 0) after bias and activation - the forward
+ * Linear + ReLU of src/modules/common_nn.py:15-20 leaves its derivative behind in M N / 8 bytes.
+ * gate_bits (optional): read, C[m][n] = 0 where its bit is clear - the input gradient through that
+ * ReLU, gated as it is produced, without re-reading the M x N activations.  The masks are fetched
+ * by scalar loads and applied as lane selects: the gated product runs at the speed of the plain one.
+ * M >= 32 and 16-byte aligned operands with multiple-of-4 strides are required (PSVAE_EINVAL
+ * otherwise: use psvae_gemm_f32 with cmask). */
+size_t psvae_gemm_f32_bits_words(int M, int N);
+int psvae_gemm_f32_bits(int M, int N, int K, const float *A, int64_t sa_m, int64_t sa_k,
+                        const float *B, int64_t sb_k, int64_t sb_n, float *C, int64_t ldc,
+                        const float *bias, int act, uint64_t *relu_bits, const uint64_t *gate_bits,
+                        void *stream);
+
 /* out[n] (+)= sum_m x[m][n] * [mask[m][n] > 0] (mask optional, same ld as x);
  * deterministic two-stage reduction through `workspace`.  The bias gradient of a Linear. */
 size_t psvae_colsum_workspace_bytes(int M, int N);

@@ -255,10 +255,11 @@ extern "C" size_t psvae_gemm_f32_workspace_bytes(int M, int N, int K, int split_
     return tall > panel ? tall : panel;
 }
 
-extern "C" int psvae_gemm_f32(int M, int N, int K, const float *A, const float *amask, int64_t sa_m,
-                              int64_t sa_k, const float *B, int64_t sb_k, int64_t sb_n, float *C, int64_t ldc,
-                              const float *bias, float *rowsum, const float *cmask, int act, int accumulate,
-                              int split_k, void *workspace, size_t workspace_bytes, void *stream) {
+static int gemm_impl(int M, int N, int K, const float *A, const float *amask, int64_t sa_m,
+                     int64_t sa_k, const float *B, int64_t sb_k, int64_t sb_n, float *C, int64_t ldc,
+                     const float *bias, float *rowsum, const float *cmask, int act, int accumulate,
+                     int split_k, void *workspace, size_t workspace_bytes, void *stream,
+                     unsigned long long *relu_bits, const unsigned long long *gate_bits) {
     PSVAE_REQUIRE(M >= 0 && N >= 0 && K >= 0, PSVAE_EINVAL, "psvae_gemm_f32: negative dimension");
     if (M == 0 || N == 0) return PSVAE_OK;
     PSVAE_REQUIRE(C != nullptr && (K == 0 || (A != nullptr && B != nullptr)), PSVAE_EINVAL,
@@ -267,7 +268,7 @@ extern "C" int psvae_gemm_f32(int M, int N, int K, const float *A, const float *
     PSVAE_REQUIRE(act == PSVAE_ACT_NONE || act == PSVAE_ACT_RELU, PSVAE_EINVAL, "psvae_gemm_f32: bad act %d", act);
     hipStream_t s = (hipStream_t)stream;
     const int n_ext0 = N + (rowsum ? 1 : 0);
-    if (split_k == 0 && sa_m == 1 && sb_n == 1 && amask == nullptr && M <= TK_MAX && n_ext0 <= TK_MAX &&
+    if (split_k == 0 && !relu_bits && !gate_bits && sa_m == 1 && sb_n == 1 && amask == nullptr && M <= TK_MAX && n_ext0 <= TK_MAX &&
         K >= TALLK_MIN_K && M % 4 == 0 && N % 4 == 0 && sa_k % 4 == 0 && sb_k % 4 == 0 && sa_k >= M && sb_k >= N &&
         psvae_aligned16(A) && psvae_aligned16(B) && psvae_aligned16(workspace)) {
         const int split = tallk_split(K, n_ext0);
@@ -279,6 +280,7 @@ extern "C" int psvae_gemm_f32(int M, int N, int K, const float *A, const float *
         g.A = A, g.amask = nullptr, g.sa_m = sa_m, g.sa_k = sa_k, g.B = B, g.sb_k = sb_k, g.sb_n = sb_n;
         g.C = C, g.ldc = ldc, g.bias = bias, g.rowsum = rowsum, g.cmask = cmask, g.act = act, g.accumulate = accumulate;
         g.split_k = split, g.ws = (float *)workspace, g.c_vec = 0, g.nt_m = g.nt_n = 1, g.bn = 0, g.wn = 1;
+        g.relu_bits = nullptr, g.gate_bits = nullptr, g.bits_ng = 0;
         g.tail_begin = K / TK_BK * TK_BK;   // the kernel takes whole k-tiles, the reduce kernel the rows left over
         g.k_chunk = psvae_cdiv(psvae_cdiv(g.tail_begin, split), TK_BK) * TK_BK;
         g.split_k = psvae_cdiv(g.tail_begin, g.k_chunk);
@@ -324,6 +326,12 @@ extern "C" int psvae_gemm_f32(int M, int N, int K, const float *A, const float *
     g.B = B, g.sb_k = sb_k, g.sb_n = sb_n;
     g.C = C, g.ldc = ldc, g.bias = bias, g.rowsum = rowsum, g.cmask = cmask, g.act = act;
     g.accumulate = accumulate, g.split_k = split_k, g.k_chunk = k_chunk, g.ws = (float *)workspace, g.tail_begin = K;
+    g.relu_bits = relu_bits, g.gate_bits = gate_bits, g.bits_ng = psvae_cdiv(N, 32);
+    if (relu_bits || gate_bits) {
+        PSVAE_REQUIRE((tile64 || panel) && split_k == 1 && g.c_vec != 0 && rowsum == nullptr, PSVAE_EINVAL,
+                      "psvae_gemm_f32_bits: needs the 16-byte-aligned kernels, no K split and no rowsum "
+                      "(M=%d N=%d K=%d split_k=%d)", M, N, K, split_k);
+    }
     if (tile64) {
         g.nt_m = psvae_cdiv(M, 64), g.nt_n = psvae_cdiv(g.n_ext, 64), g.bn = 64, g.wn = 2;
         const long long blocks = (long long)psvae_cdiv((long long)g.nt_m * split_k, 8) * 8 * g.nt_n;
@@ -368,4 +376,24 @@ extern "C" int psvae_gemm_f32(int M, int N, int K, const float *A, const float *
         PSVAE_CHECK_LAUNCH("psvae_gemm_f32 (split-K reduce)");
     }
     return PSVAE_OK;
+}
+
+extern "C" int psvae_gemm_f32(int M, int N, int K, const float *A, const float *amask, int64_t sa_m,
+                              int64_t sa_k, const float *B, int64_t sb_k, int64_t sb_n, float *C, int64_t ldc,
+                              const float *bias, float *rowsum, const float *cmask, int act, int accumulate,
+                              int split_k, void *workspace, size_t workspace_bytes, void *stream) {
+    return gemm_impl(M, N, K, A, amask, sa_m, sa_k, B, sb_k, sb_n, C, ldc, bias, rowsum, cmask, act, accumulate, split_k,
+                     workspace, workspace_bytes, stream, nullptr, nullptr);
+}
+
+extern "C" size_t psvae_gemm_f32_bits_words(int M, int N) {
+    return M <= 0 || N <= 0 ? 0 : (size_t)psvae_cdiv(M, 32) * (size_t)psvae_cdiv(N, 32) * 16;
+}
+
+extern "C" int psvae_gemm_f32_bits(int M, int N, int K, const float *A, int64_t sa_m, int64_t sa_k, const float *B,
+                                   int64_t sb_k, int64_t sb_n, float *C, int64_t ldc, const float *bias, int act,
+                                   uint64_t *relu_bits, const uint64_t *gate_bits, void *stream) {
+    PSVAE_REQUIRE(relu_bits != nullptr || gate_bits != nullptr, PSVAE_EINVAL, "psvae_gemm_f32_bits: no bit array given");
+    return gemm_impl(M, N, K, A, nullptr, sa_m, sa_k, B, sb_k, sb_n, C, ldc, bias, nullptr, nullptr, act, 0, 1, nullptr, 0,
+                     stream, (unsigned long long *)relu_bits, (const unsigned long long *)gate_bits);
 }

@@ -42,6 +42,12 @@ struct GemmArgs {
     int nt_m, nt_n, bn;   // tiles and column-tile width
     int wn;               // wave grid of the panel kernel: 1 = 4 x 1, 2 = 2 x 2
     int tail_begin;       // rows tail_begin .. K-1 of the contraction are added by the reduce kernel (K: none)
+    // Sign bits of the result, one 64-bit lane mask per (32 x 32 tile, row group i, component): see
+    // psvae_gemm_f32_bits.  relu_bits: written (result > 0); gate_bits: read, the result is zeroed
+    // where its bit is clear.  Vector panel path without K split only.
+    unsigned long long *relu_bits;
+    const unsigned long long *gate_bits;
+    int bits_ng;          // 32-column groups per row of C: ceil(N / 32)
 };
 
 __device__ __forceinline__ void epilogue_store(const GemmArgs &g, int row, int col, float v) {

@@ -265,6 +265,17 @@ __global__ __launch_bounds__(THREADS, (MASK || WN > 1 || TN > 5) ? 2 : PSVAE_PAN
             ro[i] = rows_full ? (unsigned)(((long long)(m0 + wave_m * 32 + prow + 8 * i) * ld + n0 + wave_n * TN * 32 + pc4) * 4)
                               : 0u;
         char *out_b = reinterpret_cast<char *>(out);
+        // Sign bits (never with a K split): 16 lane masks per 32 x 32 tile, indexed [row group of 32]
+        // [column group of 32][i][component] - lane (prow, pc4) of row group i owns row prow + 8 i,
+        // columns pc4 .. pc4 + 3, in the full-tile path and in the edge path alike.
+        const bool wave_has_rows = m0 + wave_m * 32 < g.M;   // (a wave below the last row owns no row group of the bit array)
+        const bool put_bits = !split && g.relu_bits != nullptr && wave_has_rows;
+        const bool get_bits = !split && g.gate_bits != nullptr && wave_has_rows;
+        // (the index is made wave-uniform for the compiler, so that the masks are fetched by scalar
+        // loads: no vector registers, and no queueing behind the vector stores of the tile before)
+        const int bits_row = ((m0 + wave_m * 32) >> 5) * g.bits_ng;
+        auto tile_bits = [&](int cbase) { return __builtin_amdgcn_readfirstlane((bits_row + (cbase >> 5)) * 16); };
+        auto uniform_mask = [&](const unsigned long long *p) { return *p; };
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int cbase = n0 + (wave_n * TN + j) * 32;
@@ -284,6 +295,21 @@ __global__ __launch_bounds__(THREADS, (MASK || WN > 1 || TN > 5) ? 2 : PSVAE_PAN
                         if (g.act == PSVAE_ACT_RELU)   // one v_med3_f32 per element
                             v.x = __builtin_amdgcn_fmed3f(v.x, 0.f, inf), v.y = __builtin_amdgcn_fmed3f(v.y, 0.f, inf),
                             v.z = __builtin_amdgcn_fmed3f(v.z, 0.f, inf), v.w = __builtin_amdgcn_fmed3f(v.w, 0.f, inf);
+                    }
+                    if (get_bits) {
+                        const unsigned long long *gp = g.gate_bits + tile_bits(cbase) + 4 * i;
+                        v.x = __builtin_amdgcn_inverse_ballot_w64(uniform_mask(gp)) ? v.x : 0.f;
+                        v.y = __builtin_amdgcn_inverse_ballot_w64(uniform_mask(gp + 1)) ? v.y : 0.f;
+                        v.z = __builtin_amdgcn_inverse_ballot_w64(uniform_mask(gp + 2)) ? v.z : 0.f;
+                        v.w = __builtin_amdgcn_inverse_ballot_w64(uniform_mask(gp + 3)) ? v.w : 0.f;
+                    }
+                    if (put_bits) {
+                        const unsigned long long bx = __ballot(v.x > 0.f), by = __ballot(v.y > 0.f);
+                        const unsigned long long bz = __ballot(v.z > 0.f), bw = __ballot(v.w > 0.f);
+                        if (lane == 0) {
+                            unsigned long long *bp = g.relu_bits + tile_bits(cbase) + 4 * i;
+                            bp[0] = bx, bp[1] = by, bp[2] = bz, bp[3] = bw;
+                        }
                     }
                     *reinterpret_cast<float4 *>(out_b + ro[i] + 128 * j) = v;
                 }
@@ -313,6 +339,39 @@ __global__ __launch_bounds__(THREADS, (MASK || WN > 1 || TN > 5) ? 2 : PSVAE_PAN
             for (int i = 0; i < 4; ++i) {
                 const int row = m0 + wave_m * 32 + prow + 8 * i;
                 float4 v = *reinterpret_cast<const float4 *>(patch + (prow + 8 * i) * EPI_STRIDE + pc4);
+                if (put_bits || get_bits) {   // wave-uniform; every lane takes part in the lane masks
+                    const bool in = row < g.M && col < g.N;
+                    const float4 b4 = bias4[j];
+                    v.x += b4.x, v.y += b4.y, v.z += b4.z, v.w += b4.w;
+                    if (g.act == PSVAE_ACT_RELU)
+                        v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+                    if (use_old) {
+                        const float4 o = old4[i];
+                        v.x += o.x, v.y += o.y, v.z += o.z, v.w += o.w;
+                    }
+                    if (get_bits) {
+                        const unsigned long long *gp = g.gate_bits + tile_bits(cbase) + 4 * i;
+                        v.x = __builtin_amdgcn_inverse_ballot_w64(uniform_mask(gp)) ? v.x : 0.f;
+                        v.y = __builtin_amdgcn_inverse_ballot_w64(uniform_mask(gp + 1)) ? v.y : 0.f;
+                        v.z = __builtin_amdgcn_inverse_ballot_w64(uniform_mask(gp + 2)) ? v.z : 0.f;
+                        v.w = __builtin_amdgcn_inverse_ballot_w64(uniform_mask(gp + 3)) ? v.w : 0.f;
+                    }
+                    if (use_gate) {
+                        const float4 mk = gate4[i];
+                        v.x = mk.x > 0.f ? v.x : 0.f, v.y = mk.y > 0.f ? v.y : 0.f;
+                        v.z = mk.z > 0.f ? v.z : 0.f, v.w = mk.w > 0.f ? v.w : 0.f;
+                    }
+                    if (put_bits) {
+                        const unsigned long long bx = __ballot(in && v.x > 0.f), by = __ballot(in && v.y > 0.f);
+                        const unsigned long long bz = __ballot(in && v.z > 0.f), bw = __ballot(in && v.w > 0.f);
+                        if (lane == 0) {
+                            unsigned long long *bp = g.relu_bits + tile_bits(cbase) + 4 * i;
+                            bp[0] = bx, bp[1] = by, bp[2] = bz, bp[3] = bw;
+                        }
+                    }
+                    if (in) *reinterpret_cast<float4 *>(out + (long long)row * ld + col) = v;
+                    continue;
+                }
                 if (row >= g.M || col >= col_lim) continue;
                 if (split) {
                     *reinterpret_cast<float4 *>(out + (long long)row * ld + col) = v;

@@ -80,6 +80,23 @@ void gemm(int64_t M, int64_t N, int64_t K, const Tensor &A, const OptTensor &ama
           "psvae_gemm_f32");
 }
 
+// the same product with the ReLU decisions as bits: see psvae_gemm_f32_bits (bit tensors are int64 storage)
+void gemm_bits(int64_t M, int64_t N, int64_t K, const Tensor &A, int64_t sa_m, int64_t sa_k, const Tensor &B, int64_t sb_k,
+               int64_t sb_n, Tensor C, int64_t ldc, const OptTensor &bias, bool relu, OptTensor relu_bits,
+               const OptTensor &gate_bits) {
+    const char *fn = "psvae_gemm_f32_bits";
+    const size_t words = psvae_gemm_f32_bits_words((int)M, (int)N);
+    auto bits = [&](const OptTensor &t) -> uint64_t * {
+        if (!t.has_value() || !t->defined()) return nullptr;
+        TORCH_CHECK(t->is_cuda() && t->scalar_type() == at::kLong && t->is_contiguous() && (size_t)t->numel() >= words, fn,
+                    ": a bit array is a contiguous int64 GPU tensor of at least ", words, " words");
+        return reinterpret_cast<uint64_t *>(t->data_ptr<int64_t>());
+    };
+    check(psvae_gemm_f32_bits((int)M, (int)N, (int)K, f32(A, fn), sa_m, sa_k, f32(B, fn), sb_k, sb_n, f32_mut(C, fn), ldc,
+                              f32(bias, fn), relu ? PSVAE_ACT_RELU : PSVAE_ACT_NONE, bits(relu_bits), bits(gate_bits),
+                              cur_stream(C)), fn);
+}
+
 void gine_aggregate_fwd(const Tensor &x, const Tensor &table, const Tensor &row_ptr, const Tensor &col, const Tensor &cls,
                         Tensor out) {
     const char *fn = "psvae_gine_aggregate_fwd";
@@ -285,6 +302,8 @@ TORCH_LIBRARY(psvae, m) {
     m.def("gemm(int M, int N, int K, Tensor A, Tensor? amask, int sa_m, int sa_k, Tensor B, int sb_k, int sb_n, "
           "Tensor(a!) C, int ldc, Tensor? bias, Tensor(b!)? rowsum, Tensor? cmask, bool relu, bool accumulate, "
           "int split_k) -> ()", &gemm);
+    m.def("gemm_bits(int M, int N, int K, Tensor A, int sa_m, int sa_k, Tensor B, int sb_k, int sb_n, Tensor(a!) C, int ldc, "
+          "Tensor? bias, bool relu, Tensor(b!)? relu_bits, Tensor? gate_bits) -> ()", &gemm_bits);
     m.def("gine_aggregate_fwd(Tensor x, Tensor table, Tensor row_ptr, Tensor col, Tensor cls, Tensor(a!) out) -> ()",
           &gine_aggregate_fwd);
     m.def("gine_aggregate_bwd(Tensor x, Tensor table, Tensor g, Tensor t_row_ptr, Tensor t_col, Tensor t_cls, Tensor? add, "

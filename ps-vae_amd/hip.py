@@ -64,6 +64,8 @@ _SIGNATURES = {
     'psvae_link_ce_bwd_input': (_c_int, [_c_int, _c_int, _c_int, _p, _p, _p, _p, _c_int, _p]),
     'psvae_pair_combine_bwd': (_c_int, [_c_int, _c_int, _p, _c_int, _p, _c_int, _c_int, _p, _p, _p, _p, _p, _p, _c_int, _p,
                                         _c_int, _p]),
+    'psvae_gemm_f32_bits_words': (_c_size, [_c_int, _c_int]),
+    'psvae_gemm_f32_bits': (_c_int, [_c_int] * 3 + [_p, _c_i64, _c_i64, _p, _c_i64, _c_i64, _p, _c_i64, _p, _c_int, _p, _p, _p]),
     'psvae_token_ce_workspace_bytes': (_c_size, [_c_int]),
     'psvae_token_ce_fwd': (_c_int, [_c_int, _c_int, _p, _c_i64, _p, _c_int, _p, _c_i64, _p, _p, _p, _c_size, _p]),
     'psvae_link_infer': (_c_int, [_c_int, _c_int, _p, _c_f32, _c_int, _p, _p, _p, _p]),
@@ -285,6 +287,22 @@ def gemm(M, N, K, A, sa_m, sa_k, B, sb_k, sb_n, C, ldc, bias=None, relu=False, a
     _count()
     with _Prof('gemm_f32_kernel', 2.0 * M * N * K, tag):
         ops().gemm(M, N, K, A, amask, sa_m, sa_k, B, sb_k, sb_n, C, ldc, bias, rowsum, cmask, relu, accumulate, split_k)
+
+
+def gemm_bits_words(M, N):
+    """64-bit words of the sign-bit array of an [M, N] result (psvae_gemm_f32_bits_words)."""
+    return ((M + 31) // 32) * ((N + 31) // 32) * 16
+
+
+def gemm_bits(M, N, K, A, sa_m, sa_k, B, sb_k, sb_n, C, ldc, bias=None, relu=False, relu_bits=None, gate_bits=None):
+    """psvae_gemm_f32_bits: C = act(A B + bias) leaving (C > 0) behind as bits (relu_bits, int64 storage)
+    and / or zeroed where the bits of gate_bits are clear."""
+    tag = None
+    if PROFILE is not None:
+        tag = (M, N, K, 'k' if sa_k == 1 else 'm', 'k' if sb_k == 1 else 'n', False, False)
+    _count()
+    with _Prof('gemm_f32_kernel', 2.0 * M * N * K, tag):
+        ops().gemm_bits(M, N, K, A, sa_m, sa_k, B, sb_k, sb_n, C, ldc, bias, relu, relu_bits, gate_bits)
 
 
 def affine_merge_fwd(w_last, b_last, w_out, b_out, w_eff, b_eff):

@@ -219,22 +219,29 @@ class _GineEncoder(Function):
             w0 = w0.contiguous()
             x0 = torch.empty(V, H, dtype=torch.float32, device=dev)
             hip.gemm(V, H, Din, x_in, _ld(x_in), 1, w0, 1, Din, x0, H, bias=b0)
+        # The ReLU decisions of every layer's first Linear as bits (V H / 8 bytes per layer): the
+        # backward gates its gradient with them instead of re-reading h
+        use_bits = V >= 32 and any(ctx.needs_input_grad)
+        bits = torch.empty(t, hip.gemm_bits_words(V, H), dtype=torch.int64, device=dev) if use_bits else None
         prev = x0
         for i in range(t):
             hip.gine_aggregate_fwd(prev, table, csr.row_ptr, csr.col, csr.cls, a[i])
-            hip.gemm(V, H, H, a[i], H, 1, w1, 1, H, h[i], H, bias=b1, relu=True)
+            if use_bits:
+                hip.gemm_bits(V, H, H, a[i], H, 1, w1, 1, H, h[i], H, bias=b1, relu=True, relu_bits=bits[i])
+            else:
+                hip.gemm(V, H, H, a[i], H, 1, w1, 1, H, h[i], H, bias=b1, relu=True)
             if RELU_TRACE is not None:
                 RELU_TRACE.append(h[i].detach())
             slot = all_x[:, i * H:(i + 1) * H]
             hip.gemm(V, H, H, h[i], H, 1, w2, 1, H, slot, t * H, bias=b2)
             prev = slot
         ctx.csr, ctx.t, ctx.only_last = csr, t, only_last
-        ctx.save_for_backward(x_in, w0, table, w1, w2, x0, all_x, a, h)
+        ctx.save_for_backward(x_in, w0, table, w1, w2, x0, all_x, a, h, bits)
         return all_x[:, (t - 1) * H:] if only_last else all_x
 
     @staticmethod
     def backward(ctx, g_all):
-        x_in, w0, table, w1, w2, x0, all_x, a, h = ctx.saved_tensors
+        x_in, w0, table, w1, w2, x0, all_x, a, h, bits = ctx.saved_tensors
         csr, t = ctx.csr, ctx.t
         V, H = x0.shape
         dev = x0.device
@@ -254,7 +261,10 @@ class _GineEncoder(Function):
         g_table = torch.empty_like(table)
         for i in range(t - 1, -1, -1):
             g_i = last if i == t - 1 else gx[i]
-            hip.gemm(V, H, H, g_i, _ld(g_i), 1, w2, H, 1, gh[i], H, cmask=h[i])   # through the last Linear + ReLU
+            if bits is not None:                                                # through the last Linear + ReLU
+                hip.gemm_bits(V, H, H, g_i, _ld(g_i), 1, w2, H, 1, gh[i], H, gate_bits=bits[i])
+            else:
+                hip.gemm(V, H, H, g_i, _ld(g_i), 1, w2, H, 1, gh[i], H, cmask=h[i])
             hip.gemm(V, H, H, gh[i], H, 1, w1, H, 1, ga, H)                     # through the first Linear
             first = i == t - 1
             if i > 0:

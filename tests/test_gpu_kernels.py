@@ -221,6 +221,49 @@ def test_gemm_small_products_on_64x64_tiles(M, N, K, ldc, a_kc, b_kc):
         assert bool((rest == 0.25).all()), 'columns beyond N were written'
 
 
+@pytest.mark.parametrize('M,N,K,ldc', [(749, 300, 300, 300), (20000, 300, 300, 300), (100, 44, 68, 44), (64, 64, 64, 64),
+                                       (4096, 200, 200, 200), (33, 300, 100, 1200), (9000, 328, 328, 328), (650, 300, 300, 300),
+                                       (95009, 300, 300, 300)])
+def test_gemm_relu_bits_and_bit_gate(M, N, K, ldc):
+    """psvae_gemm_f32_bits: the forward Linear + ReLU leaves (result > 0) behind as bits in the
+    documented layout, with a result bit-identical to the plain call; the input-gradient product
+    gated by those bits is bit-identical to the one gated by the full activations (cmask)."""
+    from ps_vae_amd import hip
+    d = dev()
+    g = torch.Generator(device=d).manual_seed(M + N)
+    x = torch.randn(M, K, device=d, generator=g)
+    w = torch.randn(N, K, device=d, generator=g) * 0.1
+    b = torch.randn(N, device=d, generator=g)
+    words = hip.gemm_bits_words(M, N)
+    guard = torch.full((words + 4096,), -1, dtype=torch.int64, device=d)     # nothing behind the array may be written
+    bits = guard[:words]
+    hbuf = torch.full((M, ldc), 9.0, device=d)
+    hip.gemm_bits(M, N, K, x, K, 1, w, 1, K, hbuf, ldc, bias=b, relu=True, relu_bits=bits)
+    plain = torch.full((M, ldc), 9.0, device=d)
+    hip.gemm(M, N, K, x, K, 1, w, 1, K, plain, ldc, bias=b, relu=True, split_k=1)
+    assert torch.equal(hbuf, plain)
+    # decode: word ((r/32) * NG + c/32) * 16 + 4 i + comp, bit l -> row 32 (r/32) + (l >> 3) + 8 i, col 32 (c/32) + 4 (l & 7) + comp
+    ng = (N + 31) // 32
+    rows = torch.arange(M, device=d)[:, None].expand(M, N)
+    cols = torch.arange(N, device=d)[None, :].expand(M, N)
+    i, lrow = (rows % 32) // 8, (rows % 32) % 8
+    comp, lcol = (cols % 32) % 4, (cols % 32) // 4
+    word = ((rows // 32) * ng + cols // 32) * 16 + 4 * i + comp
+    lane = lrow * 8 + lcol
+    got = (bits[word] >> lane) & 1
+    assert torch.equal(got.bool(), hbuf[:, :N] > 0), 'bit layout'
+    assert bool((guard[words:] == -1).all()), 'wrote behind the bit array'
+    # gradient through the ReLU: gate by bits == gate by the activations
+    gy = torch.randn(M, N, device=d, generator=g)
+    w2 = torch.randn(N, N, device=d, generator=g) * 0.1
+    by_bits = torch.full((M, ldc), 3.0, device=d)
+    by_mask = torch.full((M, ldc), 3.0, device=d)
+    hip.gemm_bits(M, N, N, gy, N, 1, w2, N, 1, by_bits, ldc, gate_bits=bits)
+    hip.gemm(M, N, N, gy, N, 1, w2, N, 1, by_mask, ldc, cmask=hbuf, split_k=1)
+    assert torch.equal(by_bits, by_mask)
+    close(by_bits[:, :N], (gy.double() @ w2.double()) * (hbuf[:, :N] > 0), what='gated input gradient')
+
+
 def test_gemm_random_shapes_and_forms():
     """Eighty seeded random products across the dispatch boundaries (64 x 64 tiles / 128-row panels /
     2 x 2 wave grid / scalar-load kernel, automatic and explicit K splits): random operand layouts,
