@@ -44,16 +44,28 @@ def recording_gemm(M, N, K, A, sa_m, sa_k, Bm, sb_k, sb_n, C, ldc, bias=None, re
                      amask=amask, split_k=split_k, rowsum=rowsum, cmask=cmask)
 
 
+real_bits = hip.gemm_bits
+
+
+def recording_gemm_bits(M, N, K, A, sa_m, sa_k, Bm, sb_k, sb_n, C, ldc, bias=None, relu=False, relu_bits=None,
+                        gate_bits=None):
+    # recorded with the flag slots of a plain call: 'B' = leaves sign bits behind, 'G' = gated by sign bits
+    calls.append((M, N, K, sa_m, sa_k, sb_k, sb_n, ldc, bias is not None, relu, False, False,
+                  'B' if relu_bits is not None else 'G', False, False))
+    return real_bits(M, N, K, A, sa_m, sa_k, Bm, sb_k, sb_n, C, ldc, bias=bias, relu=relu, relu_bits=relu_bits,
+                     gate_bits=gate_bits)
+
+
 batch = data.collate_ids(np.arange(B))
 for _ in range(2):      # the second step is the recorded one (first-call set-up is over)
     calls.clear()
-    hip.gemm = recording_gemm
+    hip.gemm, hip.gemm_bits = recording_gemm, recording_gemm_bits
     for mod in list(sys.modules.values()):
         if getattr(mod, 'hip', None) is hip:
             pass
     model.zero_grad()
     model.training_step(batch, 0).backward()
-    hip.gemm = real_gemm
+    hip.gemm, hip.gemm_bits = real_gemm, real_bits
 torch.cuda.synchronize()
 
 uniq = {}
@@ -76,9 +88,16 @@ for c, count in uniq.items():
     cmask = torch.randn(C.numel(), device=dev) if has_cmask else None
     rowsum = torch.zeros(M, device=dev) if has_rowsum else None
 
+    bits = torch.zeros(hip.gemm_bits_words(M, N), dtype=torch.int64, device=dev) if split_k in ('B', 'G') else None
+
     def run():
-        real_gemm(M, N, K, A, sa_m, sa_k, Bm, sb_k, sb_n, C, ldc, bias=bias, relu=relu, accumulate=acc, amask=amask,
-                  split_k=split_k, rowsum=rowsum, cmask=cmask)
+        if split_k == 'B':
+            real_bits(M, N, K, A, sa_m, sa_k, Bm, sb_k, sb_n, C, ldc, bias=bias, relu=relu, relu_bits=bits)
+        elif split_k == 'G':
+            real_bits(M, N, K, A, sa_m, sa_k, Bm, sb_k, sb_n, C, ldc, bias=bias, relu=relu, gate_bits=bits)
+        else:
+            real_gemm(M, N, K, A, sa_m, sa_k, Bm, sb_k, sb_n, C, ldc, bias=bias, relu=relu, accumulate=acc, amask=amask,
+                      split_k=split_k, rowsum=rowsum, cmask=cmask)
     for _ in range(2):
         run()
     torch.cuda.synchronize()
@@ -102,6 +121,6 @@ print('  total_us   each_us  n |      M     N      K  A    B   flags')
 for tot, us, count, c in rows[:TOP]:
     M, N, K, sa_m, sa_k, sb_k, sb_n, ldc, has_bias, relu, acc, has_amask, split_k, has_rowsum, has_cmask = c
     flags = ''.join(f for f, on in (('b', has_bias), ('r', relu), ('+', acc), ('m', has_amask), ('s', has_rowsum),
-                                    ('g', has_cmask)) if on)
+                                    ('g', has_cmask), ('B', split_k == 'B'), ('G', split_k == 'G')) if on)
     print(f'{tot:10.1f} {us:9.1f} {count:2d} | {M:6d} {N:5d} {K:6d}  {"k" if sa_k == 1 else "m"}    '
           f'{"k" if sb_k == 1 else "n"}   {flags:6s} {2.0 * M * N * K / us / 1e6:6.1f} TF')
