@@ -149,13 +149,15 @@ int tallk_split(int K, int n_ext) {
     return s < 1 ? 1 : (s > cap ? cap : s);
 }
 
-// 92 160 bytes of dynamic LDS: above the default limit, so the attribute is raised once per process
+// 92 160 bytes of dynamic LDS: above the default limit, so the attribute is raised once per device
 int launch_tallk(const TallKArgs &t, hipStream_t s) {
     const size_t lds = (size_t)TK_STAGES * TK_BK * (TK_LDA + TK_LDB) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};
+    int device = 0;
+    (void)hipGetDevice(&device);
+    if (device < 0 || device >= 64 || !attr_set[device]) {
         (void)hipFuncSetAttribute((const void *)gemm_tallk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
+        if (device >= 0 && device < 64) attr_set[device] = true;
     }
     // with two halves the chunk count is padded to a multiple of 8 (blocks b, b + 8 pair up)
     const int chunks_launched = t.halves == 2 ? psvae_cdiv(t.chunks, 8) * 8 : t.chunks;
