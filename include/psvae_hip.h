@@ -12,7 +12,11 @@
  *     argument (nothing was launched), or a positive hipError_t from the runtime.
  *     psvae_last_error() returns a thread-local message for the last non-zero return.
  *   - All pointers are DEVICE pointers unless a name ends in _host.  The caller owns every
- *     buffer; the library allocates nothing, keeps no state between calls and is re-entrant.
+ *     buffer; the library allocates nothing and is re-entrant.  It keeps no state between calls
+ *     apart from two per-device facts looked up once under a mutex: the address of the fixed
+ *     scratch array of psvae_gine_aggregate_bwd_noalloc and the raised dynamic-LDS limit of the
+ *     tall-K product kernel.  Both are keyed by the CURRENT device: make the device that owns the
+ *     buffers current before a call.
  *   - Work is enqueued on `stream` (a hipStream_t passed as void*); nothing synchronises.
  *   - Matrices are row-major float32; `ld*` are row strides in ELEMENTS.
  *   - int32 index arrays; bond classes are uint8 (0 = no bond .. 3 = triple,
@@ -132,6 +136,34 @@ int psvae_embed_atom_onehot(int V, const int32_t *x, const int32_t *xp, const in
 int psvae_embedding_fwd(int V, int D, int n_rows, const int32_t *ids, const float *table, float *out,
                         void *stream);
 int psvae_onehot_f32(int V, const int32_t *ids, float *out, int ld, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Deterministic table gradients of embedding lookups (the backward of nn.Embedding at
+ * src/modules/vae_piece_decoder.py:25-27, 65-69, 78): g_table[r] = sum of g[v] over the entries v
+ * whose id is r.  psvae_key_sort puts the entries in id order once per batch (stable counting
+ * sort, integers only); psvae_keyed_row_sum then adds, for every table row, its run of gathered
+ * rows of g in a fixed order (units of `chunk` entries, then the units of a row).  No float
+ * atomics, no [entries x rows] indicator matrix; equal calls give equal bits.
+ *
+ * psvae_key_sort: up to three id arrays k0, k1, k2 [V] over the same entries with table sizes
+ * n0, n1, n2 (ids outside a table are clamped into it, as in every entry point that takes ids;
+ * pass NULL / 0 for unused tables) are sorted into ONE permutation over the stacked table
+ * (table t's rows follow those of table t-1, R = n0 + n1 + n2 <= 8192 rows):
+ *   perm     [n_tables * V]  entry indices 0..V-1, grouped by stacked row, ascending inside a row
+ *   row_off  [R + 1]         entries of stacked row r are perm[row_off[r] .. row_off[r+1])
+ *   unit_off [R + 1]         prefix sum of ceil(entries of row r / chunk): the work units of the sum
+ * psvae_keyed_row_sum: out[r] = sum over i in [row_off[r], row_off[r+1]) of g[perm[i]], rows of H
+ * floats (H, ldg, ldo multiples of 4; 16-byte aligned); rows without entries get zeros.
+ * `entries` = length of perm, `chunk` = the value given to psvae_key_sort.
+ * ---------------------------------------------------------------------------------- */
+size_t psvae_key_sort_workspace_bytes(int V, int n_rows_total);
+int psvae_key_sort(int V, int n_tables, const int32_t *k0, const int32_t *k1, const int32_t *k2,
+                   int n0, int n1, int n2, int chunk, int32_t *perm, int32_t *row_off,
+                   int32_t *unit_off, void *workspace, size_t workspace_bytes, void *stream);
+size_t psvae_keyed_row_sum_workspace_bytes(long long entries, int R, int H, int chunk);
+int psvae_keyed_row_sum(int R, int H, long long entries, int chunk, const float *g, int ldg,
+                        const int32_t *perm, const int32_t *row_off, const int32_t *unit_off,
+                        float *out, int ldo, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * GINE aggregation, the message/aggregate half of torch_geometric.nn.GINEConv as called at
@@ -359,7 +391,7 @@ int psvae_link_ce_bwd_input(int P, int F, int C, const float *dlogits, const flo
  * vocabulary padded to a multiple of 4 so that the products on either side take the 16-byte
  * loaders): times g_loss * loss[1] it is the gradient; counts[0] = #rows,
  * counts[1] = #{r : first argmax == gold[r]} (src/modules/vae_piece_decoder.py:120-122).
- * V, ldd <= 1024.  Sums run in a fixed order.
+ * Sums run in a fixed order.  (Rows wider than 1024 columns are read three times instead of once.)
  * ---------------------------------------------------------------------------------- */
 size_t psvae_token_ce_workspace_bytes(int R);
 int psvae_token_ce_fwd(int R, int V, const float *logits, int64_t ld, const int32_t *gold, int ignore_index,

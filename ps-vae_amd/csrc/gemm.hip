@@ -248,8 +248,11 @@ using namespace psvae_gemm;
 extern "C" size_t psvae_gemm_f32_workspace_bytes(int M, int N, int K, int split_k) {
     if (M <= 0 || N <= 0) return 0;
     size_t tall = 0;   // the tall-K kernel may take the product (decided from the strides at the call)
-    if (split_k == 0 && M <= TK_MAX && N + 1 <= TK_MAX && K >= TALLK_MIN_K)
-        tall = (size_t)tallk_split(K, N + 1) * (size_t)M * (size_t)(N + 4) * sizeof(float);
+    if (split_k == 0 && M <= TK_MAX && N <= TK_MAX && K >= TALLK_MIN_K) {
+        // (with or without the row-sum column: the chunk cap differs at N == 160)
+        const int a = tallk_split(K, N), b = tallk_split(K, N + 1);
+        tall = (size_t)(a > b ? a : b) * (size_t)M * (size_t)(N + 4) * sizeof(float);
+    }
     split_k = resolve_split(M, N, K, split_k);
     const size_t panel = split_k <= 1 ? 0 : (size_t)split_k * (size_t)M * (size_t)(N + 4) * sizeof(float);
     return tall > panel ? tall : panel;

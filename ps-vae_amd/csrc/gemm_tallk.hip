@@ -13,6 +13,8 @@
 // B tile is preset to 1: the row sums (bias gradient) come out of the same MFMAs.  Slabs are summed
 // by gemm_splitk_reduce_kernel, which also adds the last K % 16 rows.
 // ------------------------------------------------------------------------------------------
+#include <mutex>
+
 #include "gemm_common.h"
 
 namespace psvae_gemm {
@@ -152,12 +154,25 @@ int tallk_split(int K, int n_ext) {
 // 92 160 bytes of dynamic LDS: above the default limit, so the attribute is raised once per device
 int launch_tallk(const TallKArgs &t, hipStream_t s) {
     const size_t lds = (size_t)TK_STAGES * TK_BK * (TK_LDA + TK_LDB) * sizeof(float);
-    static bool attr_set[64] = {};
+    static bool attr_set[64] = {};   // per device, under attr_mu (forward and autograd threads both launch)
+    static std::mutex attr_mu;
     int device = 0;
-    (void)hipGetDevice(&device);
-    if (device < 0 || device >= 64 || !attr_set[device]) {
-        (void)hipFuncSetAttribute((const void *)gemm_tallk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (device >= 0 && device < 64) attr_set[device] = true;
+    hipError_t e = hipGetDevice(&device);
+    if (e != hipSuccess) {
+        psvae_set_error("psvae_gemm_f32 (tall-K): hipGetDevice: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    {
+        std::lock_guard<std::mutex> lock(attr_mu);
+        if (device < 0 || device >= 64 || !attr_set[device]) {
+            e = hipFuncSetAttribute((const void *)gemm_tallk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) {   // not marked: the next call tries again
+                psvae_set_error("psvae_gemm_f32 (tall-K): raising the dynamic LDS limit to %zu bytes on device %d: %s", lds,
+                                device, hipGetErrorString(e));
+                return (int)e;
+            }
+            if (device >= 0 && device < 64) attr_set[device] = true;
+        }
     }
     // with two halves the chunk count is padded to a multiple of 8 (blocks b, b + 8 pair up)
     const int chunks_launched = t.halves == 2 ? psvae_cdiv(t.chunks, 8) * 8 : t.chunks;

@@ -80,6 +80,57 @@ __global__ __launch_bounds__(CE_THREADS) void token_ce_kernel(int R, int V, cons
     }
 }
 
+// The same for vocabularies beyond 64 * CE_MAX_PER_LANE classes: the row does not fit the lanes'
+// registers, so it is read three times (maximum, sum of exponentials, gradient row; the second and
+// third read hit the cache).  Same reduction order across lanes, same partials.
+__global__ __launch_bounds__(CE_THREADS) void token_ce_wide_kernel(int R, int V, const float *__restrict__ x, long long ld,
+                                                                   const int *__restrict__ gold, int ignore,
+                                                                   float *__restrict__ dx, long long ldd,
+                                                                   CePartial *__restrict__ part) {
+    __shared__ CePartial sh[CE_WAVES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float loss = 0.f;
+    int count = 0, correct = 0;
+    for (long long r = (long long)blockIdx.x * CE_WAVES + wave; r < R; r += (long long)gridDim.x * CE_WAVES) {
+        const float *row = x + r * ld;
+        float mx = -__builtin_inff();
+        int arg = V;
+        for (int c = lane; c < V; c += 64) {
+            const float v = row[c];
+            if (v > mx) mx = v, arg = c;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float om = __shfl_xor(mx, off);
+            const int oa = __shfl_xor(arg, off);
+            if (om > mx || (om == mx && oa < arg)) mx = om, arg = oa;
+        }
+        float sum = 0.f;
+        for (int c = lane; c < V; c += 64) sum += __expf(row[c] - mx);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+        const int g = gold[r];
+        const bool live = g != ignore;
+        const float inv = 1.f / sum;
+        float *drow = dx + r * ldd;
+        for (int c = lane; c < ldd; c += 64)
+            drow[c] = (c < V && live) ? __expf(row[c] - mx) * inv - (c == g ? 1.f : 0.f) : 0.f;
+        if (live) {
+            const float xg = (g >= 0 && g < V) ? row[g] : 0.f;
+            loss += __logf(sum) + mx - xg;
+            count += 1;
+            correct += arg == g ? 1 : 0;
+        }
+    }
+    if (lane == 0) sh[wave] = CePartial{loss, count, correct};
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        CePartial p = sh[0];
+        for (int w = 1; w < CE_WAVES; ++w) p.loss += sh[w].loss, p.count += sh[w].count, p.correct += sh[w].correct;
+        part[blockIdx.x] = p;
+    }
+}
+
 // One workgroup: thread t sums partials t, t + 256, ... in that order, then the 256 sums are added
 // pairwise through LDS in a fixed tree: the result depends on the number of partials only.
 __global__ __launch_bounds__(CE_THREADS) void token_ce_finish_kernel(int blocks, const CePartial *__restrict__ part,
@@ -120,12 +171,10 @@ extern "C" int psvae_token_ce_fwd(int R, int V, const float *logits, int64_t ld,
                                   float *dlogits, int64_t ldd, float *loss, int32_t *counts, void *workspace,
                                   size_t workspace_bytes, void *stream) {
     PSVAE_REQUIRE(R >= 0 && V >= 1, PSVAE_EINVAL, "psvae_token_ce_fwd: bad shape %d x %d", R, V);
-    PSVAE_REQUIRE(V <= 64 * CE_MAX_PER_LANE, PSVAE_ETOOLARGE, "psvae_token_ce_fwd: vocabulary %d > %d", V, 64 * CE_MAX_PER_LANE);
     PSVAE_REQUIRE(loss != nullptr && counts != nullptr, PSVAE_EINVAL, "psvae_token_ce_fwd: null output");
     PSVAE_REQUIRE(R == 0 || (logits != nullptr && gold != nullptr && dlogits != nullptr && ld >= V && ldd >= V), PSVAE_EINVAL,
                   "psvae_token_ce_fwd: null operand or a row stride below V");
-    PSVAE_REQUIRE(ldd <= 64 * CE_MAX_PER_LANE, PSVAE_ETOOLARGE, "psvae_token_ce_fwd: dlogits row stride %lld > %d",
-                  (long long)ldd, 64 * CE_MAX_PER_LANE);
+    PSVAE_REQUIRE(ldd < (1ll << 31), PSVAE_ETOOLARGE, "psvae_token_ce_fwd: dlogits row stride %lld", (long long)ldd);
     const int blocks = ce_blocks(R);
     PSVAE_REQUIRE(workspace != nullptr && workspace_bytes >= (size_t)blocks * sizeof(CePartial), PSVAE_EWORKSPACE,
                   "psvae_token_ce_fwd: workspace too small");
@@ -139,7 +188,10 @@ extern "C" int psvae_token_ce_fwd(int R, int V, const float *logits, int64_t ld,
     else if (per_lane <= 2) PSVAE_CE(2);
     else if (per_lane <= 5) PSVAE_CE(5);
     else if (per_lane <= 8) PSVAE_CE(8);
-    else PSVAE_CE(16);
+    else if (per_lane <= CE_MAX_PER_LANE) PSVAE_CE(16);
+    else
+        hipLaunchKernelGGL(token_ce_wide_kernel, dim3(blocks), dim3(CE_THREADS), 0, s, R, V, logits, (long long)ld, gold,
+                           ignore_index, dlogits, (long long)ldd, part);
 #undef PSVAE_CE
     PSVAE_CHECK_LAUNCH("psvae_token_ce_fwd");
     hipLaunchKernelGGL(token_ce_finish_kernel, dim3(1), dim3(CE_THREADS), 0, s, blocks, part, loss, counts);

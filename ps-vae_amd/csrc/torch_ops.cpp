@@ -7,9 +7,11 @@
 // and turns a non-zero status into a c10::Error carrying psvae_last_error().  Host code only: the
 // kernels live in libpsvae_hip.so (include/psvae_hip.h).
 #include <ATen/ATen.h>
+#include <c10/core/DeviceGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
 
+#include <initializer_list>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -20,6 +22,28 @@ namespace {
 
 using at::Tensor;
 using OptTensor = std::optional<Tensor>;
+
+// Every operator runs on ONE GPU, the device of its operands: the C ABI launches on the current
+// device and keys its per-device state (the fixed scratch of the no-alloc entry point, the raised
+// LDS limit of the tall-K kernel) by it, while the stream and the workspace below come from the
+// tensors' device.  So each operator first checks that all its tensors share a device and makes
+// that device current for the duration of the call.
+const Tensor *p(const Tensor &t) { return &t; }
+const Tensor *p(const OptTensor &t) { return t.has_value() && t->defined() ? &*t : nullptr; }
+
+c10::Device same_device(const char *fn, std::initializer_list<const Tensor *> tensors) {
+    const Tensor *first = nullptr;
+    for (const Tensor *t : tensors) {
+        if (t == nullptr) continue;
+        TORCH_CHECK(t->is_cuda(), fn, ": psvae operators need GPU tensors (there is no CPU fallback)");
+        if (first == nullptr) first = t;
+        TORCH_CHECK(t->device() == first->device(), fn, ": operands on different devices (", first->device(), " and ",
+                    t->device(), ")");
+    }
+    TORCH_CHECK(first != nullptr, fn, ": no tensor operand");
+    return first->device();
+}
+#define PSVAE_ON_DEVICE(fn, ...) c10::DeviceGuard device_guard_(same_device(fn, {__VA_ARGS__}))
 
 void *cur_stream(const Tensor &t) {
     TORCH_CHECK(t.is_cuda(), "psvae operators need GPU tensors (there is no CPU fallback)");
@@ -68,6 +92,7 @@ Tensor workspace(size_t nbytes, const Tensor &like, void *stream) {
 void gemm(int64_t M, int64_t N, int64_t K, const Tensor &A, const OptTensor &amask, int64_t sa_m, int64_t sa_k,
           const Tensor &B, int64_t sb_k, int64_t sb_n, Tensor C, int64_t ldc, const OptTensor &bias, OptTensor rowsum,
           const OptTensor &cmask, bool relu, bool accumulate, int64_t split_k) {
+    PSVAE_ON_DEVICE("psvae::gemm", p(A), p(amask), p(B), p(C), p(bias), p(rowsum), p(cmask));
     void *s = cur_stream(C);
     const size_t nbytes = psvae_gemm_f32_workspace_bytes((int)M, (int)N, (int)K, (int)split_k);
     void *ws = nullptr;
@@ -84,6 +109,7 @@ void gemm(int64_t M, int64_t N, int64_t K, const Tensor &A, const OptTensor &ama
 void gemm_bits(int64_t M, int64_t N, int64_t K, const Tensor &A, int64_t sa_m, int64_t sa_k, const Tensor &B, int64_t sb_k,
                int64_t sb_n, Tensor C, int64_t ldc, const OptTensor &bias, bool relu, OptTensor relu_bits,
                const OptTensor &gate_bits) {
+    PSVAE_ON_DEVICE("psvae::gemm_bits", p(A), p(B), p(C), p(bias), p(relu_bits), p(gate_bits));
     const char *fn = "psvae_gemm_f32_bits";
     const size_t words = psvae_gemm_f32_bits_words((int)M, (int)N);
     auto bits = [&](const OptTensor &t) -> uint64_t * {
@@ -99,6 +125,7 @@ void gemm_bits(int64_t M, int64_t N, int64_t K, const Tensor &A, int64_t sa_m, i
 
 void gine_aggregate_fwd(const Tensor &x, const Tensor &table, const Tensor &row_ptr, const Tensor &col, const Tensor &cls,
                         Tensor out) {
+    PSVAE_ON_DEVICE("psvae::gine_aggregate_fwd", p(x), p(table), p(row_ptr), p(col), p(cls), p(out));
     const char *fn = "psvae_gine_aggregate_fwd";
     check(psvae_gine_aggregate_fwd((int)x.size(0), (int)x.size(1), (int)table.size(0), f32(x, fn), (int)row_stride(x, fn),
                                    f32(table, fn), i32(row_ptr, fn), i32(col, fn), u8(cls, fn), f32_mut(out, fn),
@@ -108,6 +135,7 @@ void gine_aggregate_fwd(const Tensor &x, const Tensor &table, const Tensor &row_
 
 void gine_aggregate_bwd(const Tensor &x, const Tensor &table, const Tensor &g, const Tensor &t_row_ptr, const Tensor &t_col,
                         const Tensor &t_cls, const OptTensor &add, Tensor g_x, Tensor g_table, bool accumulate_table) {
+    PSVAE_ON_DEVICE("psvae::gine_aggregate_bwd", p(x), p(table), p(g), p(t_row_ptr), p(t_col), p(t_cls), p(add), p(g_x), p(g_table));
     const char *fn = "psvae_gine_aggregate_bwd";
     const int V = (int)x.size(0), H = (int)x.size(1), C = (int)table.size(0);
     void *s = cur_stream(x);
@@ -125,6 +153,7 @@ void gine_aggregate_bwd(const Tensor &x, const Tensor &table, const Tensor &g, c
 
 void pair_combine_fwd(const Tensor &a, const Tensor &b, const Tensor &c, const Tensor &src, const Tensor &dst,
                       const Tensor &graph, bool relu, Tensor out) {
+    PSVAE_ON_DEVICE("psvae::pair_combine_fwd", p(a), p(b), p(c), p(src), p(dst), p(graph), p(out));
     const char *fn = "psvae_pair_combine_fwd";
     check(psvae_pair_combine_fwd((int)src.numel(), (int)out.size(1), f32(a, fn), (int)row_stride(a, fn), f32(b, fn),
                                  (int)row_stride(b, fn), f32(c, fn), (int)row_stride(c, fn), i32(src, fn), i32(dst, fn),
@@ -135,6 +164,7 @@ void pair_combine_fwd(const Tensor &a, const Tensor &b, const Tensor &c, const T
 
 void pair_combine_bwd(const Tensor &g_out, const OptTensor &out, bool relu, const Tensor &src, const Tensor &dst,
                       const Tensor &pair_ptr, const Tensor &node_begin, const Tensor &node_end, Tensor g_ab, Tensor g_c) {
+    PSVAE_ON_DEVICE("psvae::pair_combine_bwd", p(g_out), p(out), p(src), p(dst), p(pair_ptr), p(node_begin), p(node_end), p(g_ab), p(g_c));
     const char *fn = "psvae_pair_combine_bwd";
     const int B = (int)g_c.size(0), F = (int)g_c.size(1);
     const bool any = src.numel() > 0;
@@ -149,6 +179,7 @@ void pair_combine_bwd(const Tensor &g_out, const OptTensor &out, bool relu, cons
 
 void link_ce_fwd(const Tensor &hid, const Tensor &W, const OptTensor &b, const Tensor &golden, Tensor logits, Tensor dlogits,
                  Tensor loss, Tensor n_correct) {
+    PSVAE_ON_DEVICE("psvae::link_ce_fwd", p(hid), p(W), p(b), p(golden), p(logits), p(dlogits), p(loss), p(n_correct));
     const char *fn = "psvae_link_ce_fwd";
     const int P = (int)hid.size(0), F = (int)hid.size(1);
     void *s = cur_stream(W);
@@ -162,6 +193,7 @@ void link_ce_fwd(const Tensor &hid, const Tensor &W, const OptTensor &b, const T
 }
 
 void link_ce_bwd_input(const Tensor &dlogits, const Tensor &W, const Tensor &g_loss, Tensor g_hid) {
+    PSVAE_ON_DEVICE("psvae::link_ce_bwd_input", p(dlogits), p(W), p(g_loss), p(g_hid));
     const char *fn = "psvae_link_ce_bwd_input";
     const int P = (int)dlogits.size(0);
     check(psvae_link_ce_bwd_input(P, (int)W.size(1), (int)dlogits.size(1), f32(dlogits, fn), f32(W, fn), f32(g_loss, fn),
@@ -178,12 +210,14 @@ const float *f32c(const Tensor &t, const char *what) {   // contiguous
 const float *f32c(const OptTensor &t, const char *what) { return t.has_value() && t->defined() ? f32c(*t, what) : nullptr; }
 
 void segment_sum_fwd(const Tensor &x, const Tensor &seg_begin, const Tensor &seg_end, Tensor out) {
+    PSVAE_ON_DEVICE("psvae::segment_sum_fwd", p(x), p(seg_begin), p(seg_end), p(out));
     const char *fn = "psvae_segment_sum_fwd";
     check(psvae_segment_sum_fwd((int)out.size(0), (int)x.size(1), f32(x, fn), (int)row_stride(x, fn), i32(seg_begin, fn),
                                 i32(seg_end, fn), f32_mut(out, fn), (int)row_stride(out, fn), cur_stream(out)), fn);
 }
 
 void segment_sum_bwd(const Tensor &g_out, const Tensor &seg_begin, const Tensor &seg_end, Tensor g_x) {
+    PSVAE_ON_DEVICE("psvae::segment_sum_bwd", p(g_out), p(seg_begin), p(seg_end), p(g_x));
     const char *fn = "psvae_segment_sum_bwd";
     check(psvae_segment_sum_bwd((int)g_out.size(0), (int)g_out.size(1), f32(g_out, fn), (int)row_stride(g_out, fn),
                                 i32(seg_begin, fn), i32(seg_end, fn), f32_mut(g_x, fn), (int)row_stride(g_x, fn),
@@ -191,6 +225,7 @@ void segment_sum_bwd(const Tensor &g_out, const Tensor &seg_begin, const Tensor 
 }
 
 void rsample_kl_fwd(const Tensor &mean, const Tensor &lv_pre, const Tensor &eps, Tensor z, Tensor kl) {
+    PSVAE_ON_DEVICE("psvae::rsample_kl_fwd", p(mean), p(lv_pre), p(eps), p(z), p(kl));
     const char *fn = "psvae_rsample_kl_fwd";
     check(psvae_rsample_kl_fwd((int)mean.size(0), (int)mean.size(1), f32c(mean, fn), f32c(lv_pre, fn), f32c(eps, fn),
                                const_cast<float *>(f32c(z, fn)), f32_mut(kl, fn), cur_stream(z)), fn);
@@ -198,6 +233,7 @@ void rsample_kl_fwd(const Tensor &mean, const Tensor &lv_pre, const Tensor &eps,
 
 void rsample_kl_bwd(const Tensor &mean, const Tensor &lv_pre, const Tensor &eps, const OptTensor &g_z, const OptTensor &g_kl,
                     Tensor g_mean, Tensor g_lv_pre) {
+    PSVAE_ON_DEVICE("psvae::rsample_kl_bwd", p(mean), p(lv_pre), p(eps), p(g_z), p(g_kl), p(g_mean), p(g_lv_pre));
     const char *fn = "psvae_rsample_kl_bwd";
     check(psvae_rsample_kl_bwd((int)mean.size(0), (int)mean.size(1), f32c(mean, fn), f32c(lv_pre, fn), f32c(eps, fn),
                                f32c(g_z, fn), f32(g_kl, fn), const_cast<float *>(f32c(g_mean, fn)),
@@ -206,6 +242,7 @@ void rsample_kl_bwd(const Tensor &mean, const Tensor &lv_pre, const Tensor &eps,
 
 void token_ce_fwd(const Tensor &logits, const Tensor &gold, int64_t ignore_index, int64_t n_classes, Tensor dlogits, Tensor loss,
                   Tensor counts) {
+    PSVAE_ON_DEVICE("psvae::token_ce_fwd", p(logits), p(gold), p(dlogits), p(loss), p(counts));
     const char *fn = "psvae_token_ce_fwd";
     const int R = (int)logits.size(0), V = (int)n_classes;
     TORCH_CHECK(V >= 1 && V <= logits.size(1) && dlogits.size(0) == R && dlogits.size(1) >= V, fn, ": n_classes / dlogits shape");
@@ -221,6 +258,7 @@ void token_ce_fwd(const Tensor &logits, const Tensor &gold, int64_t ignore_index
 
 void embed_trans_fwd(const Tensor &x, const Tensor &xp, const Tensor &xq, int64_t n_atom, int64_t n_piece, int64_t n_pos,
                      const Tensor &T, Tensor out) {
+    PSVAE_ON_DEVICE("psvae::embed_trans_fwd", p(x), p(xp), p(xq), p(T), p(out));
     const char *fn = "psvae_embed_trans_fwd";
     TORCH_CHECK(T.dim() == 2 && T.size(0) == n_atom + n_piece + n_pos && T.size(1) == out.size(1), fn,
                 ": T must be a [n_atom + n_piece + n_pos, H] table");
@@ -233,18 +271,58 @@ void embed_trans_fwd(const Tensor &x, const Tensor &xp, const Tensor &xq, int64_
 
 void embed_atom_onehot(const Tensor &x, const Tensor &xp, const Tensor &xq, int64_t n_atom, int64_t n_piece, int64_t n_pos,
                        Tensor out) {
+    PSVAE_ON_DEVICE("psvae::embed_atom_onehot", p(x), p(xp), p(xq), p(out));
     const char *fn = "psvae_embed_atom_onehot";
     check(psvae_embed_atom_onehot((int)x.numel(), i32(x, fn), i32(xp, fn), i32(xq, fn), (int)n_atom, (int)n_piece, (int)n_pos,
                                   const_cast<float *>(f32c(out, fn)), (int)out.size(1), cur_stream(out)), fn);
 }
 
+void key_sort(const Tensor &k0, const OptTensor &k1, const OptTensor &k2, int64_t n0, int64_t n1, int64_t n2, int64_t chunk,
+              Tensor perm, Tensor row_off, Tensor unit_off) {
+    const char *fn = "psvae_key_sort";
+    PSVAE_ON_DEVICE("psvae::key_sort", p(k0), p(k1), p(k2), p(perm), p(row_off), p(unit_off));
+    const bool h1 = k1.has_value() && k1->defined(), h2 = k2.has_value() && k2->defined();
+    TORCH_CHECK(h1 || !h2, fn, ": the third id array needs the second");
+    const int tables = 1 + (h1 ? 1 : 0) + (h2 ? 1 : 0);
+    const int V = (int)k0.numel();
+    const int64_t R = n0 + (h1 ? n1 : 0) + (h2 ? n2 : 0);
+    TORCH_CHECK((!h1 || k1->numel() == V) && (!h2 || k2->numel() == V), fn, ": id arrays differ in length");
+    TORCH_CHECK(perm.numel() == (int64_t)tables * V && row_off.numel() == R + 1 && unit_off.numel() == R + 1, fn,
+                ": perm must hold tables * V entries, row_off / unit_off R + 1");
+    void *s = cur_stream(perm);
+    const size_t nbytes = psvae_key_sort_workspace_bytes(V, (int)R);
+    void *ws = nullptr;
+    Tensor hold;
+    if (nbytes) hold = workspace(nbytes, perm, s), ws = hold.data_ptr();
+    check(psvae_key_sort(V, tables, V ? i32(k0, fn) : nullptr, h1 && V ? i32(*k1, fn) : nullptr, h2 && V ? i32(*k2, fn) : nullptr,
+                         (int)n0, (int)n1, (int)n2, (int)chunk, const_cast<int32_t *>(i32(perm, fn)),
+                         const_cast<int32_t *>(i32(row_off, fn)), const_cast<int32_t *>(i32(unit_off, fn)), ws, nbytes, s), fn);
+}
+
+void keyed_row_sum(const Tensor &g, const Tensor &perm, const Tensor &row_off, const Tensor &unit_off, int64_t chunk, Tensor out) {
+    const char *fn = "psvae_keyed_row_sum";
+    PSVAE_ON_DEVICE("psvae::keyed_row_sum", p(g), p(perm), p(row_off), p(unit_off), p(out));
+    const int R = (int)row_off.numel() - 1, H = (int)out.size(1);
+    TORCH_CHECK(out.dim() == 2 && out.size(0) == R && g.dim() == 2 && g.size(1) == H && unit_off.numel() == R + 1, fn,
+                ": out must be [rows of row_off, width of g]");
+    const int64_t entries = perm.numel();
+    void *s = cur_stream(out);
+    const size_t nbytes = psvae_keyed_row_sum_workspace_bytes(entries, R, H, (int)chunk);
+    Tensor hold = workspace(nbytes, out, s);
+    check(psvae_keyed_row_sum(R, H, entries, (int)chunk, entries ? f32(g, fn) : nullptr, entries ? (int)row_stride(g, fn) : H,
+                              i32(perm, fn), i32(row_off, fn), i32(unit_off, fn), f32_mut(out, fn), (int)row_stride(out, fn),
+                              hold.data_ptr(), nbytes, s), fn);
+}
+
 void embedding_fwd(const Tensor &ids, const Tensor &table, Tensor out) {
+    PSVAE_ON_DEVICE("psvae::embedding_fwd", p(ids), p(table), p(out));
     const char *fn = "psvae_embedding_fwd";
     check(psvae_embedding_fwd((int)ids.numel(), (int)table.size(1), (int)table.size(0), i32(ids, fn), f32c(table, fn),
                               const_cast<float *>(f32c(out, fn)), cur_stream(out)), fn);
 }
 
 void onehot(const Tensor &ids, Tensor out) {
+    PSVAE_ON_DEVICE("psvae::onehot", p(ids), p(out));
     const char *fn = "psvae_onehot_f32";
     check(psvae_onehot_f32((int)ids.numel(), i32(ids, fn), const_cast<float *>(f32c(out, fn)), (int)out.size(1),
                            cur_stream(out)), fn);
@@ -252,6 +330,7 @@ void onehot(const Tensor &ids, Tensor out) {
 
 void affine_merge_fwd(const Tensor &w_last, const OptTensor &b_last, const Tensor &w_out, const OptTensor &b_out, Tensor w_eff,
                       Tensor b_eff) {
+    PSVAE_ON_DEVICE("psvae::affine_merge_fwd", p(w_last), p(b_last), p(w_out), p(b_out), p(w_eff), p(b_eff));
     const char *fn = "psvae_affine_merge_fwd";
     check(psvae_affine_merge_fwd((int)w_last.size(0), (int)w_last.size(1), (int)w_out.size(1), f32c(w_last, fn),
                                  f32c(b_last, fn), f32c(w_out, fn), f32c(b_out, fn), const_cast<float *>(f32c(w_eff, fn)),
@@ -260,6 +339,7 @@ void affine_merge_fwd(const Tensor &w_last, const OptTensor &b_last, const Tenso
 
 void affine_merge_bwd(const Tensor &w_last, const Tensor &w_out, const OptTensor &b_out, const Tensor &g_w_eff,
                       const Tensor &g_b_eff, Tensor g_w_last, Tensor g_w_out, OptTensor g_b_out) {
+    PSVAE_ON_DEVICE("psvae::affine_merge_bwd", p(w_last), p(w_out), p(b_out), p(g_w_eff), p(g_b_eff), p(g_w_last), p(g_w_out), p(g_b_out));
     const char *fn = "psvae_affine_merge_bwd";
     check(psvae_affine_merge_bwd((int)w_last.size(0), (int)w_last.size(1), (int)w_out.size(1), f32c(w_last, fn),
                                  f32c(w_out, fn), f32c(b_out, fn), f32c(g_w_eff, fn), f32c(g_b_eff, fn),
@@ -268,6 +348,7 @@ void affine_merge_bwd(const Tensor &w_last, const Tensor &w_out, const OptTensor
 }
 
 void colsum(const Tensor &x, const OptTensor &mask, Tensor out, bool accumulate) {
+    PSVAE_ON_DEVICE("psvae::colsum", p(x), p(mask), p(out));
     const char *fn = "psvae_colsum_f32";
     const int M = (int)x.size(0), N = (int)x.size(1);
     const int64_t ld = row_stride(x, fn);
@@ -282,6 +363,7 @@ void colsum(const Tensor &x, const OptTensor &mask, Tensor out, bool accumulate)
 
 void gru_seq_fwd(const Tensor &gi, const Tensor &h0, const Tensor &w_hh, const OptTensor &b_hh, Tensor hall, Tensor gates,
                  Tensor ghn) {
+    PSVAE_ON_DEVICE("psvae::gru_seq_fwd", p(gi), p(h0), p(w_hh), p(b_hh), p(hall), p(gates), p(ghn));
     const char *fn = "psvae_gru_seq_fwd";
     check(psvae_gru_seq_fwd((int)gi.size(0), (int)gi.size(1), (int)gi.size(2) / 3, f32c(gi, fn), f32c(h0, fn), f32c(w_hh, fn),
                             f32c(b_hh, fn), const_cast<float *>(f32c(hall, fn)), const_cast<float *>(f32c(gates, fn)),
@@ -290,6 +372,7 @@ void gru_seq_fwd(const Tensor &gi, const Tensor &h0, const Tensor &w_hh, const O
 
 void gru_seq_bwd(const Tensor &gates, const Tensor &ghn, const Tensor &hall, const Tensor &g_out, const Tensor &w_hh_t,
                  Tensor dgi, Tensor dgh, Tensor dh0) {
+    PSVAE_ON_DEVICE("psvae::gru_seq_bwd", p(gates), p(ghn), p(hall), p(g_out), p(w_hh_t), p(dgi), p(dgh), p(dh0));
     const char *fn = "psvae_gru_seq_bwd";
     check(psvae_gru_seq_bwd((int)gates.size(0), (int)gates.size(1), (int)gates.size(2) / 3, f32c(gates, fn), f32c(ghn, fn),
                             f32c(hall, fn), f32c(g_out, fn), f32c(w_hh_t, fn), const_cast<float *>(f32c(dgi, fn)),
@@ -328,6 +411,10 @@ TORCH_LIBRARY(psvae, m) {
     m.def("embed_atom_onehot(Tensor x, Tensor xp, Tensor xq, int n_atom, int n_piece, int n_pos, Tensor(a!) out) -> ()",
           &embed_atom_onehot);
     m.def("embedding_fwd(Tensor ids, Tensor table, Tensor(a!) out) -> ()", &embedding_fwd);
+    m.def("key_sort(Tensor k0, Tensor? k1, Tensor? k2, int n0, int n1, int n2, int chunk, Tensor(a!) perm, Tensor(b!) row_off, "
+          "Tensor(c!) unit_off) -> ()", &key_sort);
+    m.def("keyed_row_sum(Tensor g, Tensor perm, Tensor row_off, Tensor unit_off, int chunk, Tensor(a!) out) -> ()",
+          &keyed_row_sum);
     m.def("onehot(Tensor ids, Tensor(a!) out) -> ()", &onehot);
     m.def("affine_merge_fwd(Tensor w_last, Tensor? b_last, Tensor w_out, Tensor? b_out, Tensor(a!) w_eff, Tensor(b!) b_eff) -> ()",
           &affine_merge_fwd);

@@ -34,6 +34,10 @@ _SIGNATURES = {
     'psvae_embed_atom_onehot': (_c_int, [_c_int, _p, _p, _p, _c_int, _c_int, _c_int, _p, _c_int, _p]),
     'psvae_embedding_fwd': (_c_int, [_c_int, _c_int, _c_int, _p, _p, _p, _p]),
     'psvae_onehot_f32': (_c_int, [_c_int, _p, _p, _c_int, _p]),
+    'psvae_key_sort_workspace_bytes': (_c_size, [_c_int, _c_int]),
+    'psvae_key_sort': (_c_int, [_c_int, _c_int, _p, _p, _p, _c_int, _c_int, _c_int, _c_int, _p, _p, _p, _p, _c_size, _p]),
+    'psvae_keyed_row_sum_workspace_bytes': (_c_size, [_c_ll, _c_int, _c_int, _c_int]),
+    'psvae_keyed_row_sum': (_c_int, [_c_int, _c_int, _c_ll, _c_int, _p, _c_int, _p, _p, _p, _p, _c_int, _p, _c_size, _p]),
     'psvae_gine_aggregate_fwd': (_c_int, [_c_int, _c_int, _c_int, _p, _c_int, _p, _p, _p, _p, _p, _c_int, _p]),
     'psvae_gine_aggregate_bwd_workspace_bytes': (_c_size, [_c_int, _c_int, _c_int]),
     'psvae_gine_aggregate_bwd': (_c_int, [_c_int, _c_int, _c_int, _p, _c_int, _p, _p, _c_int, _p, _p, _p, _p,
@@ -166,6 +170,11 @@ def ptr(t, dtype=None):
         raise RuntimeError('psvae HIP ops need GPU tensors (there is no CPU fallback)')
     if dtype is not None and t.dtype != dtype:
         raise TypeError(f'expected {dtype}, got {t.dtype}')
+    # the ctypes route launches on the CURRENT device and takes its current stream (_stream()):
+    # a tensor that lives on another GPU would be touched from the wrong device
+    if t.device.index != _cur_device():
+        raise RuntimeError(f'tensor on cuda:{t.device.index} while cuda:{_cur_device()} is the current device: '
+                           'make the tensor\'s device current (torch.cuda.device) around the call')
     return ctypes.c_void_p(t.data_ptr())
 
 
@@ -377,6 +386,31 @@ def embedding_fwd(ids, table, out):
 def onehot(ids, out):
     _count()
     ops().onehot(ids, out)
+
+
+KEY_CHUNK = 256   # entries per work unit of the keyed row sum
+KEY_SORT_MAX_ROWS = 8192   # table rows psvae_key_sort accepts (all tables together)
+
+
+def key_sort(keys, sizes, chunk=KEY_CHUNK):
+    """psvae_key_sort: keys = 1..3 int32 id vectors over the same V entries, sizes = rows of their
+    tables.  Returns (perm [len(keys) * V], row_off [R + 1], unit_off [R + 1]) int32."""
+    V, dev = keys[0].numel(), keys[0].device
+    R = int(sum(sizes))
+    perm = torch.empty(len(keys) * V, dtype=torch.int32, device=dev)
+    row_off = torch.empty(R + 1, dtype=torch.int32, device=dev)
+    unit_off = torch.empty(R + 1, dtype=torch.int32, device=dev)
+    k = list(keys) + [None] * (3 - len(keys))
+    n = [int(s) for s in sizes] + [0] * (3 - len(sizes))
+    _count()
+    ops().key_sort(k[0], k[1], k[2], n[0], n[1], n[2], chunk, perm, row_off, unit_off)
+    return perm, row_off, unit_off
+
+
+def keyed_row_sum(g, perm, row_off, unit_off, out, chunk=KEY_CHUNK):
+    """out[r] = sum of g[perm[i]] over i in [row_off[r], row_off[r+1]) (psvae_keyed_row_sum)."""
+    _count()
+    ops().keyed_row_sum(g, perm, row_off, unit_off, chunk, out)
 
 
 def embed_trans_fwd(x, xp, xq, sizes, T, out):

@@ -67,7 +67,7 @@ class VAEPieceDecoder(nn.Module):
         ids = ops.EmbeddedIds(flat[0], flat[1], flat[2], self.atom_embedding.weight, self.piece_embedding.weight,
                               self.pos_embedding.weight)
         if torch.is_grad_enabled() and flat[0].numel():
-            ids.indicator()   # the backward of both encoders reads it, possibly on two streams
+            ids.sorted_keys()   # the backward of both encoders reads it, possibly on two streams
         return ids
 
     def embed_atom(self, atom_ids, piece_ids, pos_ids):

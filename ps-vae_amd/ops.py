@@ -318,17 +318,16 @@ class _EmbedAtom(Function):
         g2 = g if (g.dtype == torch.float32 and g.is_contiguous()) else g.float().contiguous()
         (na, da), (npc, dp), (nq, dq) = ctx.shapes
         V, D = g2.shape
-        rows = (na + npc + nq + 3) // 4 * 4
-        if rows > 1024 or V == 0:
-            # large vocabularies: float atomics into zero-filled tables
+        rows = na + npc + nq
+        if rows > hip.KEY_SORT_MAX_ROWS:
+            # very large vocabularies: float atomics into zero-filled tables
             ga, gp, gq = (torch.zeros(s, dtype=torch.float32, device=g2.device) for s in ctx.shapes)
             hip.embed_atom_bwd(x, xp, xq, g2, ga, gp, gq)
             return None, None, None, ga, gp, gq
-        # deterministic: indicator^T g on the GEMM, table gradients = its diagonal blocks
-        onehot = torch.empty(V, rows, dtype=torch.float32, device=g2.device)
-        hip.embed_atom_onehot(x, xp, xq, na, npc, nq, onehot)
+        # deterministic: the atoms in id order, then every table row = the sum of its run of rows of g
+        perm, row_off, unit_off = hip.key_sort((x, xp, xq), (na, npc, nq))
         full = torch.empty(rows, D, dtype=torch.float32, device=g2.device)
-        hip.gemm(rows, D, V, onehot, 1, rows, g2, D, 1, full, D, split_k=0)
+        hip.keyed_row_sum(g2, perm, row_off, unit_off, full)
         return (None, None, None, full[:na, :da], full[na:na + npc, da:da + dp],
                 full[na + npc:na + npc + nq, da + dp:])
 
@@ -340,8 +339,9 @@ def embed_atom(x, xp, xq, e_atom, e_piece, e_pos):
 
 # ------------------------------------------------------------------------ one embedding table
 class _Embedding(Function):
-    """table[ids] with a deterministic backward: the table gradient is indicator^T g on the GEMM
-    (fixed summation order), not atomic adds or a sort."""
+    """table[ids] with a deterministic backward: the entries are put in id order by a stable
+    counting sort and every table row is the sum of its run of rows of g in a fixed order
+    (hip.key_sort + hip.keyed_row_sum), not atomic adds."""
 
     @staticmethod
     def forward(ctx, ids, table):
@@ -359,14 +359,10 @@ class _Embedding(Function):
         V, D = flat.numel(), g.shape[-1]
         g2 = g.reshape(V, D)
         g2 = g2 if (g2.dtype == torch.float32 and g2.is_contiguous()) else g2.float().contiguous()
-        r4 = (ctx.rows + 3) // 4 * 4
-        if V == 0:
-            return None, torch.zeros(ctx.rows, D, dtype=torch.float32, device=g2.device)
-        ind = torch.empty(V, r4, dtype=torch.float32, device=g2.device)
-        hip.onehot(flat, ind)
-        full = torch.empty(r4, D, dtype=torch.float32, device=g2.device)
-        hip.gemm(r4, D, V, ind, 1, r4, g2, D, 1, full, D, split_k=0)
-        return None, full[:ctx.rows]
+        perm, row_off, unit_off = hip.key_sort((flat,), (ctx.rows,))
+        full = torch.empty(ctx.rows, D, dtype=torch.float32, device=g2.device)
+        hip.keyed_row_sum(g2, perm, row_off, unit_off, full)
+        return None, full
 
 
 def embedding(ids, table):
@@ -420,13 +416,13 @@ class EmbeddedIds:
         gradient accumulators live (autograd joins the two streams at the node)."""
         twin = EmbeddedIds(self.x, self.xp, self.xq, *self.tables)
         twin._block = stream_handoff(self.block_table())
-        if getattr(self, '_indicator', None) is not None:
-            twin._indicator = self._indicator
+        if getattr(self, '_sorted', None) is not None:
+            twin._sorted = self._sorted
         return twin
 
     def tensors(self):
         """Every device buffer this object owns (for record_stream on a second stream)."""
-        extra = [t for t in (getattr(self, '_indicator', None), getattr(self, '_block', None)) if t is not None]
+        extra = [t for t in (getattr(self, '_sorted', None) or ()) + (getattr(self, '_block', None),) if t is not None]
         return (self.x, self.xp, self.xq) + tuple(extra)
 
     def block_table(self):
@@ -438,18 +434,14 @@ class EmbeddedIds:
             self._block = _BlockTable.apply(*self.tables)
         return self._block
 
-    def indicator(self):
-        """[V, R4] f32, a one in the three key columns of every atom (R4 = table rows rounded
-        up to 4); built once per batch and shared by the backward of every encoder.  Call it
-        on the stream that created the ids BEFORE work forks to other streams: a backward on
-        another stream only reads it."""
-        if getattr(self, '_indicator', None) is None:
-            sizes = [int(t.shape[0]) for t in self.tables]
-            r4 = (sum(sizes) + 3) // 4 * 4
-            onehot = torch.empty(self.x.numel(), r4, dtype=torch.float32, device=self.x.device)
-            hip.embed_atom_onehot(self.x, self.xp, self.xq, sizes[0], sizes[1], sizes[2], onehot)
-            self._indicator = onehot
-        return self._indicator
+    def sorted_keys(self):
+        """(perm, row_off, unit_off) of hip.key_sort over the three id vectors: the atoms in the
+        order of the block table's rows, for the table gradient of every encoder.  Built once per
+        batch; call it on the stream that created the ids BEFORE work forks to other streams: a
+        backward on another stream only reads it."""
+        if getattr(self, '_sorted', None) is None:
+            self._sorted = hip.key_sort((self.x, self.xp, self.xq), [int(t.shape[0]) for t in self.tables])
+        return self._sorted
 
 
 class _EmbedTrans(Function):
@@ -463,16 +455,12 @@ class _EmbedTrans(Function):
 
     @staticmethod
     def backward(ctx, g):
-        # dT = indicator^T g: deterministic (split-K in fixed order), one product per encoder
+        # dT[r] = sum of g over the atoms that looked row r up: a keyed row sum over the sorted atoms
         g2 = g if (g.dtype == torch.float32 and g.is_contiguous()) else g.float().contiguous()
-        V, H = g2.shape
-        if V == 0:
-            return torch.zeros(ctx.rows, H, dtype=torch.float32, device=g2.device), None
-        onehot = ctx.ids.indicator()
-        r4 = onehot.shape[1]
-        full = torch.empty(r4, H, dtype=torch.float32, device=g2.device)
-        hip.gemm(r4, H, V, onehot, 1, r4, g2, H, 1, full, H, split_k=0)
-        return full[:ctx.rows], None
+        perm, row_off, unit_off = ctx.ids.sorted_keys()
+        full = torch.empty(ctx.rows, g2.shape[1], dtype=torch.float32, device=g2.device)
+        hip.keyed_row_sum(g2, perm, row_off, unit_off, full)
+        return full, None
 
 
 class _SplitColumns(Function):

@@ -118,6 +118,20 @@ def test_rejected_arguments_return_codes_without_touching_the_gpu():
     assert assemble(4, 100, ws_bytes=need - 1) == EWORKSPACE
     assert assemble(4, 100, ws=null) == EWORKSPACE
 
+    # keyed row sums: table sizes, strides, workspace
+    ks = L.psvae_key_sort
+    assert ks(5, 0, P, null, null, 4, 0, 0, 256, P, P, P, null, 0, null) == EINVAL          # no table
+    assert ks(5, 2, P, null, null, 4, 4, 0, 256, P, P, P, null, 0, null) == EINVAL          # second id array missing
+    assert ks(5, 1, P, null, null, 9000, 0, 0, 256, P, P, P, null, 0, null) == ETOOLARGE     # more rows than fit the counters
+    assert ks(5000, 1, P, null, null, 40, 0, 0, 256, P, P, P, null, 0, null) == EWORKSPACE   # several workgroups need histograms
+    assert L.psvae_key_sort_workspace_bytes(5000, 40) == 5 * 40 * 4 and L.psvae_key_sort_workspace_bytes(1000, 40) == 0
+    need = L.psvae_keyed_row_sum_workspace_bytes(1000, 40, 8, 256)
+    assert need == (1000 // 256 + 40) * 8 * 4
+    krs = L.psvae_keyed_row_sum
+    assert krs(40, 8, 1000, 256, P, 8, P, P, P, P, 8, P, need - 1, null) == EWORKSPACE
+    assert krs(40, 6, 1000, 256, P, 8, P, P, P, P, 8, P, need, null) == EINVAL               # width not a multiple of 4
+    assert krs(40, 8, 1000, 256, P, 4, P, P, P, P, 8, P, need, null) == EINVAL               # row stride below the width
+
     # link loss / inference helpers
     assert L.psvae_link_infer(0, 4, null, 0.5, 0, null, null, null, null) == 0
     assert ETOOLARGE == -2
@@ -132,6 +146,7 @@ def test_torch_operator_library_registers_its_operators():
     names = ['gemm', 'gine_aggregate_fwd', 'gine_aggregate_bwd', 'pair_combine_fwd', 'pair_combine_bwd',
              'link_ce_fwd', 'link_ce_bwd_input', 'segment_sum_fwd', 'segment_sum_bwd', 'rsample_kl_fwd',
              'rsample_kl_bwd', 'token_ce_fwd', 'embed_trans_fwd', 'embed_atom_onehot', 'embedding_fwd', 'onehot',
+             'key_sort', 'keyed_row_sum',
              'affine_merge_fwd', 'affine_merge_bwd', 'colsum', 'gru_seq_fwd', 'gru_seq_bwd']
     for name in names:
         assert getattr(ops, name)._schema.name == f'psvae::{name}'

@@ -627,6 +627,64 @@ def test_embedding_fwd_bwd():
     close(td.grad, table.grad, what='embedding table gradient')
 
 
+@pytest.mark.parametrize('V,sizes,H', [(0, (11, 302, 50), 8), (1, (3,), 4), (1024, (11, 302, 50), 300),
+                                        (1025, (11, 302), 100), (95398, (11, 302, 50), 300), (45056, (302,), 100),
+                                        (5000, (4000, 4000), 12)])
+def test_key_sort_and_keyed_row_sum(V, sizes, H):
+    """psvae_key_sort: the permutation is the stable sort of the entries by (table, id) - bit-exact
+    against numpy, ids outside a table clamped - and the offsets are the prefix counts;
+    psvae_keyed_row_sum: every stacked-table row is the float64 sum of its entries' rows within
+    1e-5 of the largest entry, and two calls agree bit for bit."""
+    from ps_vae_amd import hip
+    d = dev()
+    rng = np.random.default_rng(V + H)
+    keys = []
+    for t, n in enumerate(sizes):
+        k = rng.integers(-2, n + 2, size=V) if t == 0 else rng.integers(0, n, size=V)
+        if t == 0 and V > 10:
+            k[rng.random(V) < 0.7] = min(1, n - 1)          # one dominant id, like carbon among the atom types
+        keys.append(k.astype(np.int32))
+    chunk = hip.KEY_CHUNK
+    perm, row_off, unit_off = hip.key_sort([torch.from_numpy(k).to(d) for k in keys], sizes)
+    R = sum(sizes)
+    want_perm, counts = [], []
+    for k, n in zip(keys, sizes):
+        kc = np.clip(k, 0, n - 1)
+        want_perm.append(np.argsort(kc, kind='stable').astype(np.int32))
+        counts.append(np.bincount(kc, minlength=n))
+    want_perm = np.concatenate(want_perm) if V else np.zeros(0, np.int32)
+    counts = np.concatenate(counts)
+    assert np.array_equal(perm.cpu().numpy(), want_perm)
+    assert np.array_equal(row_off.cpu().numpy(), np.concatenate([[0], np.cumsum(counts)]))
+    assert np.array_equal(unit_off.cpu().numpy(), np.concatenate([[0], np.cumsum(-(-counts // chunk))]))
+    g = torch.randn(max(V, 1), H, generator=torch.Generator().manual_seed(V))[:V]
+    gd = g.to(d)
+    out = torch.full((R, H), 7.0, device=d)
+    hip.keyed_row_sum(gd, perm, row_off, unit_off, out)
+    want = torch.zeros(R, H, dtype=torch.float64)
+    base = 0
+    for k, n in zip(keys, sizes):
+        want.index_add_(0, torch.from_numpy(np.clip(k, 0, n - 1).astype(np.int64)) + base, g.double())
+        base += n
+    close(out, want, what='keyed row sum')
+    again = torch.empty(R, H, device=d)
+    hip.keyed_row_sum(gd, perm, row_off, unit_off, again)
+    assert torch.equal(out, again)
+    # a strided gradient (a column block of a wider matrix) and a strided output
+    if V and H >= 8:
+        wide = torch.randn(V, H + 8, generator=torch.Generator().manual_seed(1)).to(d)
+        out2 = torch.zeros(R, H + 4, device=d)
+        hip.keyed_row_sum(wide[:, 4:4 + H], perm, row_off, unit_off, out2[:, :H])
+        want2 = torch.zeros(R, H, dtype=torch.float64)
+        base = 0
+        for k, n in zip(keys, sizes):
+            want2.index_add_(0, torch.from_numpy(np.clip(k, 0, n - 1).astype(np.int64)) + base,
+                             wide[:, 4:4 + H].cpu().double())
+            base += n
+        close(out2[:, :H], want2, what='keyed row sum, strided')
+        assert float(out2[:, H:].abs().max()) == 0.0
+
+
 def make_pairs(B, N, seed, p=0.15):
     g = torch.Generator().manual_seed(seed)
     sel = torch.rand(B, N, N, generator=g) < p
