@@ -44,6 +44,8 @@ def parse():
     ap.add_argument('--gemm-shapes', action='store_true', help='per-shape GEMM timing table on stderr')
     ap.add_argument('--cpu-batch', type=int, default=256)
     ap.add_argument('--cpu-steps', type=int, default=30, help='CPU-baseline headline sample: about 8 s of host work')
+    ap.add_argument('--cpu-full-steps', type=int, default=2,
+                    help='CPU-baseline steps at the full batch of the headline workload (0: skip that leg)')
     return ap.parse_args()
 
 
@@ -89,7 +91,7 @@ def _cpu_leg(tok, shape, batch, steps, seed):
     return t_collate, t_model
 
 
-def cpu_baseline(tok, batch, steps):
+def cpu_baseline(tok, batch, steps, full_batch=0, full_steps=0):
     """The CPU oracle (oracle/: pure-Python collation restatement + plain PyTorch fp32 model,
     clip, Adam) on this machine's host cores, on bounded samples of the same workloads: the
     headline sample at `batch` (default 256), plus batch 32 on ZINC-shaped and QM9-shaped
@@ -102,7 +104,18 @@ def cpu_baseline(tok, batch, steps):
            'sample': f'{steps} train steps of batch {batch} (same synthetic ZINC-shaped generator), '
                      f'collation + forward + backward + clip + Adam, after 1 warm-up step',
            'collate_molecules_per_s_1core': round(batch * steps / tc, 2),
-           'model_step_molecules_per_s': round(batch * steps / tm, 2)}
+           'model_step_molecules_per_s': round(batch * steps / tm, 2),
+           'note': 'kind "port": the oracle is a restatement of the reference, not the reference itself. Its '
+                   'collation is a numpy / Python restatement that runs tens of times faster than the '
+                   'reference\'s own triple loop over torch tensor elements (about 100 molecules/s per core when '
+                   'the reference was profiled), so this baseline is conservative: the reference would be slower.'}
+    if full_batch and full_steps:
+        tc, tm = _cpu_leg(tok, 'zinc', full_batch, full_steps, 97)
+        out[f'b{full_batch}'] = {'value': round(full_batch * full_steps / (tc + tm), 2), 'unit': 'molecules/s', 'cores': cores,
+                                 'sample': f'{full_steps} train steps of batch {full_batch} (the batch of the headline '
+                                           f'workload), after 1 warm-up step',
+                                 'collate_molecules_per_s_1core': round(full_batch * full_steps / tc, 2),
+                                 'model_step_molecules_per_s': round(full_batch * full_steps / tm, 2)}
     for name, shape, b, n in (('b32_zinc', 'zinc', 32, 60), ('b32_qm9', 'qm9', 32, 120)):
         tc, tm = _cpu_leg(tok, shape, b, n, 98)
         out[name] = {'value': round(b * n / (tc + tm), 2), 'unit': 'molecules/s', 'cores': cores,
@@ -263,10 +276,17 @@ def main():
     t0 = time.perf_counter()
     stats = {'V': 0, 'E': 0, 'Ein': 0, 'P': 0}
     trace = []
+    # a step ends with the optimiser kernel on the main stream, behind everything else of the step:
+    # an event there marks the step's end on the GPU's own clock
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    bracketed = []
+    marks[0].record()
     for i in range(args.steps):
         hip.PROFILE = prof if i % 16 == 0 else (prof_shared if i % 16 == 8 else None)
+        bracketed.append(hip.PROFILE is not None)
         model.two_streams = two_streams and i % 16 != 0
         b = step()
+        marks[i + 1].record()
         trace.append(time.perf_counter())
         c = b.compact
         stats['V'] += c.num_nodes
@@ -279,6 +299,12 @@ def main():
         print('host ms per step (no sync):', [round((b - a) * 1e3, 1) for a, b in zip([t0] + trace[:-1], trace)],
               'final fence ms', round((t0 + elapsed - trace[-1]) * 1e3, 1), file=sys.stderr)
     hip.PROFILE = None
+    rccl_ranks = None
+    if world > 1 and args.backend == 'nccl':
+        # how many ranks a collective on the GPUs actually joins: one all-reduce of a one per rank
+        ones = torch.ones(1, dtype=torch.float32, device=dev)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        rccl_ranks = int(ones.item())
     final_loss = float(model.logged['reconstruct loss'].detach())
     model.two_streams = two_streams
     if world > 1:
@@ -286,6 +312,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    plain = [t for t, br in zip(step_ms, bracketed) if not br]
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
@@ -300,7 +328,14 @@ def main():
                        'batch_per_gpu': B, 'global_batch': B * world, 'parallelism': f'dp{world}',
                        'atoms_per_step': stats['V'] // args.steps, 'pairs_per_step': stats['P'] // args.steps},
             'rec_loss_last_step': round(final_loss, 5),
+            # GPU-clock duration of the timed steps that carry no kernel event brackets (the brackets cost
+            # host time and some of those steps run one stream); `value` and `ms_per_step` cover ALL steps
+            'ms_per_step_without_event_brackets': round(sum(plain) / len(plain), 3) if plain else None,
+            'steps_with_event_brackets': sum(bracketed),
         }
+        if world > 1:
+            out['rccl_ranks'] = rccl_ranks          # ranks that joined an all-reduce over RCCL (None: another backend)
+            out['collective'] = f'one flat all-reduce of {opt.sync.flat.numel()} f32 per step over {dist.get_backend()}'
         traffic, traffic_source = pmc_traffic(B)
         out.update(hip.roofline_report(prof, HBM_PEAK_GBS, MFMA_F32_PEAK_TFLOPS, traffic))
         out['traffic_source'] = traffic_source
@@ -328,7 +363,7 @@ def main():
             out['b32_qm9'] = small_batch_record(factory, tok, 'qm9', 32, 200, 30, dev)
             out['infer_10k'] = generation_record(model, dev)
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(tok, args.cpu_batch, args.cpu_steps)
+            out['cpu_baseline'] = cpu_baseline(tok, args.cpu_batch, args.cpu_steps, B, args.cpu_full_steps)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -106,25 +106,56 @@ class BPEMolDataset(torch.utils.data.Dataset):
 
 class _Loader:
     """Batches of molecule ids collated on the GPU (the DataLoader + worker processes of
-    the reference, :184-187, are not needed: there is no per-sample Python work left)."""
+    the reference, :184-187, are not needed: there is no per-sample Python work left).
 
-    def __init__(self, dataset, batch_size, shuffle, reference_layout=True, seed=None):
+    world > 1: this rank's share of every epoch, as torch's DistributedSampler deals it
+    (src/guacamol_exps/goal_directed/train.py:271): all ranks build the same order (the same
+    seed, advanced by the epoch count), `pad` repeats molecules from its start until it divides
+    by the world size, and rank r takes order[r::world] - disjoint shares and the same number of
+    steps on every rank, which the per-step gradient all-reduce needs.  pad=False (evaluation:
+    no collective inside a step) leaves the order as it is, so every molecule is seen once."""
+
+    def __init__(self, dataset, batch_size, shuffle, reference_layout=True, seed=None, rank=0, world=1, pad=True):
+        if not 0 <= rank < world:
+            raise ValueError(f'rank {rank} outside a world of {world}')
+        if world > 1 and shuffle and seed is None:
+            raise ValueError('a sharded, shuffled loader needs a seed that every rank shares')
         self.dataset, self.batch_size, self.shuffle = dataset, batch_size, shuffle
         self.reference_layout = reference_layout
+        self.seed, self.rank, self.world, self.pad = seed, rank, world, pad
+        self.epoch = 0
         self.rng = np.random.default_rng(seed)
 
+    def _share(self, n):
+        if self.world == 1:
+            return n
+        return (n + self.world - 1) // self.world if self.pad else len(range(self.rank, n, self.world))
+
     def __len__(self):
-        return (len(self.dataset) + self.batch_size - 1) // self.batch_size
+        return (self._share(len(self.dataset)) + self.batch_size - 1) // self.batch_size
+
+    def order(self):
+        """Molecule ids of the next epoch, in visiting order (this rank's share)."""
+        n = len(self.dataset)
+        if self.world == 1:
+            return self.rng.permutation(n) if self.shuffle else np.arange(n)
+        order = np.random.default_rng(self.seed + self.epoch).permutation(n) if self.shuffle else np.arange(n)
+        if self.pad and n % self.world and n:
+            order = np.concatenate([order, np.resize(order, self.world - n % self.world)])
+        return order[self.rank::self.world]
 
     def __iter__(self):
-        order = self.rng.permutation(len(self.dataset)) if self.shuffle else np.arange(len(self.dataset))
+        order = self.order()
+        self.epoch += 1
         for i in range(0, len(order), self.batch_size):
             yield self.dataset.collate_ids(order[i:i + self.batch_size], reference_layout=self.reference_layout)
 
 
 def get_dataloader(fname, tokenizer, batch_size, shuffle=False, num_workers=4, device='cuda', data=None,
-                   reference_layout=True, seed=None):
+                   reference_layout=True, seed=None, rank=0, world=1, pad=True):
     """reference_layout=False yields batches that carry only the compact layout the kernels
-    read (no padded [B,N] tensors, no host stop for the pair count): what training uses."""
+    read (no padded [B,N] tensors, no host stop for the pair count): what training uses.
+    rank / world / pad: see _Loader."""
     dataset = BPEMolDataset(fname, tokenizer, device=device, data=data)
-    return _Loader(dataset, batch_size, shuffle, reference_layout=reference_layout, seed=seed)
+    return _Loader(dataset, batch_size, shuffle, reference_layout=reference_layout, seed=seed, rank=rank, world=world,
+                   pad=pad)

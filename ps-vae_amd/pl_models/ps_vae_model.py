@@ -42,6 +42,34 @@ class PSVAEModel(nn.Module):
     def device(self):
         return next(self.parameters()).device
 
+    def hyper_parameters(self):
+        """What the reference's save_hyperparameters() keeps in a checkpoint
+        (src/pl_models/ps_vae_model.py:21: config and tokenizer), as plain data: the config dict
+        with the tokenizer object taken out and the vocabulary rows in id order."""
+        config = {k: (dict(v) if isinstance(v, dict) else v) for k, v in self.config.items()}
+        config['vae_piece_decoder'] = {k: v for k, v in config['vae_piece_decoder'].items() if k != 'tokenizer'}
+        vocab_state = getattr(self.tokenizer, 'vocab_state', None)    # (a stand-in tokenizer may not offer it)
+        return {'config': config, 'vocab': vocab_state() if vocab_state is not None else None}
+
+    @classmethod
+    def load_from_checkpoint(cls, path, map_location=None):
+        """Rebuild tokenizer and model from a checkpoint ps_vae_amd.train wrote and load its weights
+        (the reference's PSVAEModel.load_from_checkpoint, used at src/generate.py:97).  The file is
+        read with weights_only=True: tensors and plain containers only."""
+        from ..utils.tokenizer import Tokenizer
+        payload = torch.load(path, map_location='cpu', weights_only=True)
+        hp = payload.get('hyper_parameters')
+        if hp is None or hp.get('vocab') is None:
+            raise KeyError(f'{path} holds no hyper_parameters / vocabulary: build the model yourself and use '
+                           'train.load_checkpoint')
+        tokenizer = Tokenizer(pieces=hp['vocab'])
+        config = {k: (dict(v) if isinstance(v, dict) else v) for k, v in hp['config'].items()}
+        config['vae_piece_decoder']['tokenizer'] = tokenizer
+        model = cls(config, tokenizer)
+        model.load_state_dict(payload['state_dict'])
+        model.global_step = int(payload.get('global_step', 0))
+        return model.to(map_location) if map_location is not None else model
+
     def log(self, name, value, **kwargs):
         # detached, like Lightning's self.log: a logged loss must not keep the step's autograd graph
         # (and with it the parameters' gradient accumulators, which remember the stream they were

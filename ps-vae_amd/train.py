@@ -11,8 +11,18 @@
     (src/utils/nn_utils.py:126-136: patience does not run while the KL weight is annealing);
   * afterwards one pass over the test loader (trainer.test, :54).
 
+Several GPUs: one process per GPU under torchrun (the reference's own multi-GPU switch is
+single-process DataParallel, :49-50; its one torch.distributed trainer is
+src/guacamol_exps/goal_directed/train.py:159-161, 268-276, whose recipe this follows): the process
+group is RCCL ('nccl'), the device comes from LOCAL_RANK, --batch_size is the global batch and
+every rank takes batch_size / world molecules of its own share of the (identically shuffled)
+training set, the gradients are averaged by one all-reduce inside the optimiser step, the
+monitored value is reduced over the ranks' shares of the validation set, and rank 0 alone writes
+checkpoints.
+
     python -m ps_vae_amd.train --train_set train.npz --valid_set valid.npz --test_set test.npz \
         --vocab vocab.txt --save_dir ckpt --alpha 0.1 [the flags of src/train.py:57-111]
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m ps_vae_amd.train ...
 """
 import argparse
 import math
@@ -21,6 +31,7 @@ import random
 
 import numpy as np
 import torch
+import torch.distributed as dist
 
 
 def setup_seed(seed):
@@ -64,24 +75,31 @@ class VAEEarlyStopping:
 
 class ModelCheckpoint:
     """Keeps the checkpoint with the lowest monitored value (save_top_k = 1): the model's
-    state_dict under the reference's keys plus epoch / global_step / monitor value."""
+    state_dict under the reference's keys, epoch / global_step / monitor value, the optimiser
+    state and - when the model offers hyper_parameters() - what the reference's
+    save_hyperparameters() stores (config and vocabulary, src/pl_models/ps_vae_model.py:21), so
+    that PSVAEModel.load_from_checkpoint can rebuild the model from the file alone.
+    write=False (every rank but the first): the best score is tracked, nothing is written."""
 
-    def __init__(self, dirpath, monitor='val_loss'):
-        self.dirpath, self.monitor = dirpath, monitor
+    def __init__(self, dirpath, monitor='val_loss', write=True):
+        self.dirpath, self.monitor, self.write = dirpath, monitor, write
         self.best_score, self.best_path = math.inf, None
 
     def on_validation_end(self, model, epoch, global_step, current, optimizer=None):
         if self.dirpath is None or not current < self.best_score:
             return None
-        os.makedirs(self.dirpath, exist_ok=True)
         path = os.path.join(self.dirpath, f'epoch={epoch}-step={global_step}.ckpt')
-        payload = {'state_dict': {k: v.detach().cpu() for k, v in model.state_dict().items()},
-                   'epoch': epoch, 'global_step': global_step, self.monitor: current}
-        if optimizer is not None:
-            payload['optimizer'] = optimizer.state_dict()
-        torch.save(payload, path)
-        if self.best_path is not None and self.best_path != path and os.path.exists(self.best_path):
-            os.remove(self.best_path)
+        if self.write:
+            os.makedirs(self.dirpath, exist_ok=True)
+            payload = {'state_dict': {k: v.detach().cpu() for k, v in model.state_dict().items()},
+                       'epoch': epoch, 'global_step': global_step, self.monitor: current}
+            if hasattr(model, 'hyper_parameters'):
+                payload['hyper_parameters'] = model.hyper_parameters()
+            if optimizer is not None:
+                payload['optimizer'] = optimizer.state_dict()
+            torch.save(payload, path)
+            if self.best_path is not None and self.best_path != path and os.path.exists(self.best_path):
+                os.remove(self.best_path)
         self.best_score, self.best_path = current, path
         return path
 
@@ -98,9 +116,26 @@ def _logged(model, name):
     return float(v.detach()) if torch.is_tensor(v) else float(v)
 
 
+def _world():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def _rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def _reduce_device(model):
+    """Where a tensor must live to be all-reduced: on this rank's GPU under RCCL, on the host under gloo."""
+    if dist.get_backend() == 'nccl':
+        return next(model.parameters()).device
+    return torch.device('cpu')
+
+
 @torch.no_grad()
 def evaluate(model, loader, hook, name):
-    """Batch-size weighted mean of the value `hook` logs under `name` over `loader`."""
+    """Batch-size weighted mean of the value `hook` logs under `name` over `loader`; with a
+    process group, over the loaders of all ranks (sums of value x size and of sizes are
+    all-reduced, so every rank returns the same number)."""
     was_training = model.training
     model.eval()
     total, count = 0.0, 0
@@ -110,6 +145,10 @@ def evaluate(model, loader, hook, name):
         total += _logged(model, name) * n
         count += n
     model.train(was_training)
+    if _world() > 1:
+        t = torch.tensor([total, float(count)], dtype=torch.float64, device=_reduce_device(model))
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        total, count = float(t[0]), int(t[1])
     return total / count if count else math.nan
 
 
@@ -122,18 +161,27 @@ def fit(model, train_loader, valid_loader=None, test_loader=None, max_epochs=6, 
     fused_tail = hasattr(opt, 'sync')          # optim.FlatAdam: exchange + clip + Adam in step()
     if fused_tail:
         opt.max_norm = grad_clip
+    exchange = None
+    if not fused_tail and _world() > 1:        # a stock optimiser: the same flat all-reduce, ahead of the clipping
+        from .dist import FlatGradSync
+        exchange = FlatGradSync(model.parameters())
     stopper = VAEEarlyStopping(finish_anneal, patience=patience)
-    ckpt = ModelCheckpoint(save_dir, monitor)
+    ckpt = ModelCheckpoint(save_dir, monitor, write=_rank() == 0)
     history = {'monitor': [], 'lr': [], 'stopped_early': False}
     model.train()
     epoch = 0
     for epoch in range(max_epochs):
         history['lr'].append(opt.param_groups[0]['lr'])
         for i, batch in enumerate(train_loader):
-            opt.zero_grad()
+            if exchange is not None:
+                exchange.zero_grad()
+            else:
+                opt.zero_grad()
             loss = model.training_step(batch, i)
             loss.backward()
             loss = loss.detach()   # the graph must be gone before the next forward builds its own
+            if exchange is not None:
+                exchange.sync()
             if not fused_tail and grad_clip:
                 torch.nn.utils.clip_grad_norm_(model.parameters(), grad_clip)
             opt.step()
@@ -200,20 +248,49 @@ def parse(argv=None):
     return ap.parse_args(argv)
 
 
+def init_distributed(backend='nccl'):
+    """Join the process group torchrun describes (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*) before any
+    other GPU call: the device is LOCAL_RANK and RCCL is bound to it.  Returns (rank, world, device);
+    a plain `python -m ps_vae_amd.train` run is (0, 1, cuda:0 or the current device)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world <= 1:
+        return 0, 1, torch.device('cuda', torch.cuda.current_device()) if torch.cuda.is_available() else torch.device('cpu')
+    rank, local_rank = int(os.environ['RANK']), int(os.environ.get('LOCAL_RANK', '0'))
+    if backend == 'nccl':
+        torch.cuda.set_device(local_rank)
+        device = torch.device('cuda', local_rank)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+    else:
+        device = torch.device('cuda', local_rank) if torch.cuda.is_available() else torch.device('cpu')
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, device
+
+
 def main(argv=None):
     from .data import bpe_dataset
     from .pl_models import PSVAEModel
     from .utils.nn_utils import build_config
     from .utils.tokenizer import Tokenizer
-    setup_seed(2021)
     args = parse(argv)
+    rank, world, device = init_distributed()
+    setup_seed(2021)                         # the same initial weights on every rank
     tokenizer = Tokenizer(args.vocab)
-    loaders = [bpe_dataset.get_dataloader(f, tokenizer, batch_size=args.batch_size, shuffle=sh, reference_layout=False)
-               for f, sh in ((args.train_set, args.shuffle), (args.valid_set, False), (args.test_set, False))]
-    model = PSVAEModel(build_config(args, tokenizer), tokenizer).to('cuda')
+    if args.batch_size % world:
+        raise SystemExit(f'--batch_size {args.batch_size} is the global batch: it must divide by the {world} ranks')
+    per_rank = args.batch_size // world      # src/guacamol_exps/goal_directed/train.py:272
+    loaders = [bpe_dataset.get_dataloader(f, tokenizer, batch_size=per_rank, shuffle=sh, reference_layout=False,
+                                          device=device, seed=2021, rank=rank, world=world, pad=pad)
+               for f, sh, pad in ((args.train_set, args.shuffle, True), (args.valid_set, False, False),
+                                  (args.test_set, False, False))]
+    model = PSVAEModel(build_config(args, tokenizer), tokenizer).to(device)
+    torch.manual_seed(2021 + rank)           # per-rank streams for the latent noise
     result = fit(model, *loaders, max_epochs=args.epochs, grad_clip=args.grad_clip, patience=args.patience,
                  finish_anneal=finish_anneal_step(args), monitor=args.monitor, save_dir=args.save_dir)
-    print(result)
+    if rank == 0:
+        print(result)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
     return result
 
 

@@ -64,12 +64,18 @@ def synthetic_pieces(num, seed=0):
 
 
 class Tokenizer:
-    def __init__(self, vocab_path=None, num_pieces=300):
+    def __init__(self, vocab_path=None, num_pieces=300, pieces=None):
         """vocab_path: the reference's text format, one `smiles\\tatom_num\\tfreq` per line
-        (:158-166).  Without a file, `num_pieces` synthetic pieces are created."""
+        (:158-166).  pieces: the same rows as (smiles, atom_num, freq) tuples (what a checkpoint
+        stores, see vocab_state).  Without either, `num_pieces` synthetic pieces are created."""
         self.vocab_dict, self.idx2piece, self.piece2idx = {}, [], {}
         self._fragments = None
-        if vocab_path is not None:
+        if pieces is not None:
+            for smi, atom_num, freq in pieces:
+                self.vocab_dict[smi] = (int(atom_num), int(freq))
+                self.piece2idx[smi] = len(self.idx2piece)
+                self.idx2piece.append(smi)
+        elif vocab_path is not None:
             with open(vocab_path, 'r') as fin:
                 lines = fin.read().strip().split('\n')
             for line in lines:
@@ -88,6 +94,12 @@ class Tokenizer:
             self.idx2piece.append(smi)
         self.atom_pad = '<pad>'
         self.chem_vocab = GeneralVocab(atom_special=[self.atom_pad])
+
+    def vocab_state(self):
+        """The vocabulary as plain data: [smiles, atom_num, freq] per piece, in id order (the rows
+        of the vocabulary file).  Tokenizer(pieces=state) rebuilds an equal tokenizer."""
+        n = len(self.idx2piece) - 2     # without <pad> and <s>
+        return [[smi, self.vocab_dict[smi][0], self.vocab_dict[smi][1]] for smi in self.idx2piece[:n]]
 
     def tokenize(self, mol, return_idx=False):
         raise NotImplementedError('principal-subgraph tokenisation needs RDKit (src/data/mol_bpe.py:175-222)')

@@ -96,3 +96,68 @@ def test_two_ranks_on_one_gpu_stay_identical(tmp_path):
         assert torch.equal(res[0]['params'][step], res[1]['params'][step])
     assert not torch.equal(res[0]['params'][0], res[0]['params'][1])              # and the step moved them
     assert res[0]['warnings'] == [] and res[1]['warnings'] == []
+
+
+def _fit_rank(rank, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD),
+                      LOCAL_RANK='0')                  # both ranks drive GPU 0
+    import torch.distributed as dist
+    import ps_vae_amd  # noqa: F401
+    from ps_vae_amd import train
+    from ps_vae_amd.data.bpe_dataset import get_dataloader
+    from ps_vae_amd.data.synthetic import synthetic_step1
+    from ps_vae_amd.pl_models import PSVAEModel
+    from ps_vae_amd.utils.nn_utils import build_config, default_args
+    from ps_vae_amd.utils.tokenizer import Tokenizer
+    got_rank, world, dev = train.init_distributed(backend='gloo')
+    assert (got_rank, world, dev) == (rank, WORLD, torch.device('cuda', 0))
+    tok = Tokenizer()
+    train.setup_seed(2021)
+    model = PSVAEModel(build_config(default_args(), tok), tok).to(dev)
+    mols = synthetic_step1(101 + 37, seed=17, shape='zinc')
+    seen = []
+    loaders = [get_dataloader(None, tok, 16, shuffle=sh, device=dev, data=part, reference_layout=False, seed=3,
+                              rank=rank, world=world, pad=pad)
+               for part, sh, pad in ((mols[:101], True, True), (mols[101:], False, False))]
+    order = loaders[0].order                            # record the ids of every epoch as the loader deals them
+    loaders[0].order = lambda: seen.append(order().tolist()) or np.asarray(seen[-1])
+    torch.manual_seed(2021 + rank)
+    hist = train.fit(model, *loaders, max_epochs=2, grad_clip=10.0, save_dir=os.path.join(out_dir, 'ckpt'))
+    torch.cuda.synchronize()
+    torch.save({'params': torch.cat([p.detach().flatten().cpu() for p in model.parameters()]), 'seen': seen,
+                'monitor': hist['monitor'], 'steps': hist['global_step'], 'best_path': hist['best_path']},
+               os.path.join(out_dir, f'fit{rank}.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_fit_two_ranks_on_one_gpu(tmp_path):
+    """ps_vae_amd.train.fit with the HIP model as two ranks (gloo) on one GPU: disjoint shares of equal
+    length per epoch, identical parameters after two epochs, one reduced validation value, one
+    checkpoint (rank 0's) from which PSVAEModel.load_from_checkpoint rebuilds the model."""
+    ctx = multiprocessing.get_context('forkserver')
+    port = _free_port()
+    procs = [ctx.Process(target=_fit_rank, args=(r, port, str(tmp_path))) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+    alive = [p for p in procs if p.is_alive()]
+    for p in alive:
+        p.kill()
+    assert not alive, 'a rank did not finish'
+    assert [p.exitcode for p in procs] == [0] * WORLD
+    res = [torch.load(os.path.join(tmp_path, f'fit{r}.pt'), weights_only=True) for r in range(WORLD)]
+    assert torch.equal(res[0]['params'], res[1]['params'])
+    assert res[0]['steps'] == res[1]['steps'] == 2 * 4                   # ceil(51 / 16) steps per epoch
+    assert res[0]['monitor'] == res[1]['monitor'] and np.isfinite(res[0]['monitor']).all()
+    for e in range(2):
+        a, b = res[0]['seen'][e], res[1]['seen'][e]
+        assert len(a) == len(b) == 51 and sorted(set(a + b)) == list(range(101))
+    assert res[0]['seen'][0] != res[0]['seen'][1]
+    files = os.listdir(os.path.join(tmp_path, 'ckpt'))
+    assert len(files) == 1 and res[0]['best_path'].endswith(files[0])
+    from ps_vae_amd.pl_models import PSVAEModel
+    twin = PSVAEModel.load_from_checkpoint(res[0]['best_path'])
+    assert twin.global_step in (4, 8) and twin.tokenizer.num_piece_type() == 302

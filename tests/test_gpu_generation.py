@@ -139,7 +139,7 @@ def test_generation_10k_full_size_properties_and_slice_equality():
         pairs, c1, t1, order1 = dec.infer_links(z[b], x_all[a0:a1], xp_all[a0:a1], xq_all[a0:a1], ei, ea, groups, th)
         lo, hi = ptr[b], ptr[b + 1]
         assert np.array_equal(np.stack([lm[lo:hi], ln[lo:hi]], 1), pairs.cpu().numpy())
-        close(torch.from_numpy(conf[lo:hi]), c1, rel=2e-5, what=f'molecule {b} confidence')
+        close(torch.from_numpy(conf[lo:hi]), c1, what=f'molecule {b} confidence')
         srt = (order[optr[b]:optr[b + 1]] - lo).tolist()
         bonds = [(int(s), int(d), int(k)) for s, d, k in zip(e_src, e_dst, e_cls) if s < d]
         w_acc, w_blk, w_keep = assemble_ref.assemble(x_all[a0:a1].tolist(), bonds, groups,

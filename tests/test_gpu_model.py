@@ -10,6 +10,10 @@ from test_gpu_kernels import close, dev
 
 pytestmark = pytest.mark.gpu
 
+# fp32 tolerance against the reference's own golden vectors (gradients, post-step parameters),
+# relative to the tensor's largest entry
+GOLD_REL = 1e-5
+
 SMALL = dict(latent_dim=8, predictor_hidden_dim=16, node_hidden_dim=36, graph_embedding_dim=40,
              atom_embedding_dim=6, piece_embedding_dim=12, pos_embedding_dim=6, piece_hidden_dim=20)
 
@@ -98,7 +102,7 @@ def test_small_model_against_reference_golden(tokenizer, path):
         if k in no_grad:
             assert p.grad is None, k
             continue
-        close(p.grad, torch.from_numpy(gold[f'grad/{k}']), rel=2e-5, what=f'grad {k}')
+        close(p.grad, torch.from_numpy(gold[f'grad/{k}']), rel=GOLD_REL, what=f'grad {k}')
     if flat_opt is not None:
         flat_opt.step()
         total = flat_opt.grad_norm
@@ -108,7 +112,7 @@ def test_small_model_against_reference_golden(tokenizer, path):
         opt.step()
     np.testing.assert_allclose(total.item(), gold['grad_total_norm'], rtol=1e-5)
     for k, v in model.state_dict().items():
-        close(v, torch.from_numpy(gold[f'after_step/{k}']), rel=2e-5, what=f'after step {k}')
+        close(v, torch.from_numpy(gold[f'after_step/{k}']), rel=GOLD_REL, what=f'after step {k}')
 
 
 def test_flat_adam_follows_torch_adam_with_clipping():
@@ -162,16 +166,18 @@ def test_default_width_model_against_reference_golden(tokenizer):
     for name, val in [('total', loss), ('pred', pred_loss), ('rec', rec), ('piece', piece), ('edge', edge), ('kl', kl)]:
         np.testing.assert_allclose(val.item(), gold[f'loss/{name}'], rtol=1e-5, err_msg=name)
     loss.backward()
+    worst = (0.0, '')
     for k, p in model.named_parameters():
         if p.grad is None:
             assert k in set(gold['no_grad_params'].tolist())
             continue
         np.testing.assert_allclose(p.grad.norm().item(), gold[f'gradnorm/{k}'], rtol=1e-4, err_msg=k)
         # element-wise against the reference itself: every 97th entry of every gradient at the
-        # widths the kernels are tuned for, within 2e-5 of the tensor's largest entry
+        # widths the kernels are tuned for, within GOLD_REL of the tensor's largest entry
         got = p.grad.reshape(-1)[::97].cpu().numpy()
         err = np.abs(got - gold[f'gradsample/{k}']).max()
-        assert err <= 2e-5 * float(gold[f'gradmax/{k}']), f'{k}: {err:.3e} vs max {float(gold[f"gradmax/{k}"]):.3e}'
+        worst = max(worst, (err / float(gold[f'gradmax/{k}']), k))
+        assert err <= GOLD_REL * float(gold[f'gradmax/{k}']), f'{k}: {err:.3e} vs max {float(gold[f"gradmax/{k}"]):.3e}'
     (opt,), _ = model.configure_optimizers()          # also packs the gradients just produced
     opt.max_norm = 10.0
     opt.step()
@@ -179,18 +185,18 @@ def test_default_width_model_against_reference_golden(tokenizer):
     for k, v in model.state_dict().items():
         want = gold[f'after_step_sample/{k}']
         got = v.reshape(-1)[::97].cpu().numpy()
-        assert np.abs(got - want).max() <= 2e-5 * max(np.abs(want).max(), 1e-30), f'after step {k}'
+        assert np.abs(got - want).max() <= GOLD_REL * max(np.abs(want).max(), 1e-30), f'after step {k}'
+    print(f'default widths vs the reference: largest sampled gradient error {worst[0]:.2e} of its tensor\'s largest entry ({worst[1]})')
 
 
 def test_default_width_batch_256_against_oracle(tokenizer):
     """A larger batch through the compact path vs the CPU oracle on the reference layout of
     the same collation: every loss and every parameter gradient.
 
-    Yardstick: the oracle evaluated in float64.  Two fp32 implementations that sum in
-    different orders cannot agree to 1e-5 on every gradient of a network this deep (the fp32
-    CPU oracle itself is off the float64 result by up to ~3e-3 of the tensor's largest entry
-    on decoder.piece_embedding.weight), so each gradient must be within 1e-5 relative of the
-    float64 value OR at least as close to it as twice the fp32 CPU oracle's own distance.
+    Yardstick: the oracle evaluated in float64 (the fp32 CPU oracle itself is off the float64
+    result by up to ~3e-3 of the tensor's largest entry on decoder.piece_embedding.weight, so it
+    cannot be the yardstick): every gradient must be within 1e-5 of the float64 value, relative to
+    the tensor's largest entry.  The fp32 CPU oracle's own distance is printed beside it.
 
     ReLU kinks: with ~16 M ReLU inputs in this batch a few lie within fp32 rounding of zero,
     and an implementation that rounds differently takes the other side of the kink (the loss
@@ -282,7 +288,7 @@ def test_default_width_batch_256_against_oracle(tokenizer):
     ref64f.weighted_loss(plf, recf, klf).backward()
 
     refp, refp64, refp64f = dict(ref.named_parameters()), dict(ref64.named_parameters()), dict(ref64f.named_parameters())
-    worst = (0.0, '')
+    worst, worst_cpu = (0.0, ''), (0.0, '')
     for k, p in model.named_parameters():
         if refp[k].grad is None:
             assert p.grad is None, k
@@ -292,12 +298,12 @@ def test_default_width_batch_256_against_oracle(tokenizer):
         err_gpu = (p.grad.cpu().double() - g64f).abs().max().item()
         err_cpu = (refp[k].grad.double() - g64).abs().max().item()
         worst = max(worst, (err_gpu / scale, k))
-        # 1e-5 of the tensor's largest entry, or - on the few tensors where fp32 summation order
-        # alone moves the fp32 CPU oracle further than that from float64 - twice that distance
-        assert err_gpu <= max(1e-5 * scale, 2.0 * err_cpu), \
+        worst_cpu = max(worst_cpu, (err_cpu / scale, k))
+        assert err_gpu <= 1e-5 * scale, \
             f'grad {k}: GPU {err_gpu / scale:.2e} of the largest entry from the float64 oracle under the GPU\'s ' \
             f'ReLU decisions; fp32 CPU oracle {err_cpu / scale:.2e} from the plain float64 oracle; {flips} ReLU flips'
-    print(f'{flips} ReLU flips; largest GPU gradient error {worst[0]:.2e} ({worst[1]})')
+    print(f'{flips} ReLU flips; largest GPU gradient error {worst[0]:.2e} of its tensor\'s largest entry ({worst[1]}); '
+          f'the fp32 CPU oracle\'s own largest distance from float64: {worst_cpu[0]:.2e} ({worst_cpu[1]})')
 
 
 def test_loss_curve_follows_the_oracle_over_30_steps(tokenizer):
@@ -487,6 +493,7 @@ def test_batch_32_train_step_against_oracle(tokenizer, shape):
     for k, v in l64.items():
         assert abs(got[k] - v) <= 1e-5 * abs(v), (k, got[k], v, l32[k])
     p32, p64 = dict(ref.named_parameters()), dict(ref64.named_parameters())
+    worst = (0.0, '', 0.0)
     for k, p in model.named_parameters():
         if p64[k].grad is None:
             assert p.grad is None or not bool(p.grad.any()), k
@@ -495,7 +502,9 @@ def test_batch_32_train_step_against_oracle(tokenizer, shape):
         scale = g64.abs().max().item()
         err_gpu = (p.grad.cpu().double() - g64).abs().max().item()
         err_cpu = (p32[k].grad.double() - g64).abs().max().item()
-        assert err_gpu <= max(1e-5 * scale, 2.0 * err_cpu), f'grad {k}: {err_gpu / scale:.2e} (fp32 oracle {err_cpu / scale:.2e})'
+        worst = max(worst, (err_gpu / scale, k, err_cpu / scale))
+        assert err_gpu <= 1e-5 * scale, f'grad {k}: {err_gpu / scale:.2e} (fp32 oracle {err_cpu / scale:.2e})'
+    print(f'largest GPU gradient error {worst[0]:.2e} of its tensor\'s largest entry ({worst[1]}; fp32 CPU oracle there {worst[2]:.2e})')
     g64 = {k: q.grad.clone() for k, q in p64.items() if q.grad is not None}
     norm64 = torch.nn.utils.clip_grad_norm_(ref64.parameters(), 10.0)
     torch.optim.Adam(ref64.parameters(), lr=cfg['lr']).step()
@@ -511,7 +520,7 @@ def test_batch_32_train_step_against_oracle(tokenizer, shape):
             continue
         want, got_p = p64[k].detach()[clear], p.detach().cpu().double()[clear]
         err = (got_p - want).abs().max().item()
-        assert err <= 2e-5 * max(want.abs().max().item(), 1e-3), f'{k}: {err:.3e} vs values up to {want.abs().max().item():.3e}'
+        assert err <= 1e-5 * max(want.abs().max().item(), 1e-3), f'{k}: {err:.3e} vs values up to {want.abs().max().item():.3e}'
 
 
 def test_infer_links_against_reference_golden(tokenizer):
@@ -530,7 +539,7 @@ def test_infer_links_against_reference_golden(tokenizer):
             torch.from_numpy(g['x_pos']), torch.from_numpy(g['edge_index']), torch.from_numpy(g['edge_attr']),
             groups, th)
         assert np.array_equal(pairs.cpu().numpy(), g['pairs'])
-        close(conf, torch.from_numpy(g['conf']), rel=2e-5, what='confidence')
+        close(conf, torch.from_numpy(g['conf']), what='confidence')
         assert np.array_equal(etype.cpu().numpy(), g['etype'])
         # the kept set and its order agree wherever confidences are not within rounding of
         # each other or of the threshold
@@ -629,7 +638,7 @@ def test_infer_links_batch_equals_per_molecule(tokenizer):
         lo, hi = ptr[b], ptr[b + 1]
         assert hi - lo == pairs.shape[0]
         assert np.array_equal(torch.stack([res['m'][lo:hi], res['n'][lo:hi]], 1).cpu().numpy(), pairs.cpu().numpy())
-        close(res['conf'][lo:hi], conf, rel=2e-5, what=f'molecule {b} confidence')
+        close(res['conf'][lo:hi], conf, what=f'molecule {b} confidence')
         assert np.array_equal(res['etype'][lo:hi].cpu().numpy(), etype.cpu().numpy())
         got = (res['order'][optr[b]:optr[b + 1]] - int(lo)).cpu().tolist()
         c = conf.cpu().numpy()
