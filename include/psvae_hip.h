@@ -191,6 +191,36 @@ int psvae_gine_aggregate_bwd(int V, int H, int C, const float *x, int ldx, const
                              const float *add, int ldadd, float *g_x, int ldgx, float *g_table,
                              int accumulate_table, void *workspace, size_t workspace_bytes, void *stream);
 
+/* psvae_gine_aggregate_bwd with a per-graph add: row seg_add[node_graph[j]] (row stride ld_seg_add;
+ * both NULL for none) is added to g_x[j] - the gradient of a sum pooled over each graph's nodes
+ * (src/modules/encoder.py:63-67) is one row per graph, read where it is needed instead of being
+ * spread to [V, H] first. */
+int psvae_gine_aggregate_bwd_graph_add(int V, int H, int C, const float *x, int ldx, const float *table,
+                                       const float *g, int ldg,
+                                       const int32_t *t_row_ptr, const int32_t *t_col, const uint8_t *t_cls,
+                                       const float *add, int ldadd, const float *seg_add, int ld_seg_add,
+                                       const int32_t *node_graph, float *g_x, int ldgx, float *g_table,
+                                       int accumulate_table, void *workspace, size_t workspace_bytes, void *stream);
+
+/* The same pair with the ReLU decisions carried as bits.  The message node j sends along an edge of
+ * class k is ReLU(x[j] + table[k]): its derivative depends on (j, k) only, so the forward leaves
+ * 4 C bits per float4 column of every node behind - mask_bits [V][H / 4], 16-bit words for C <= 4,
+ * 32-bit words for C <= 8 (bit 4 k + e: element e of the column under class k;
+ * psvae_gine_mask_bytes(V, H, C) bytes, aligned to its word size) - and the backward reads those instead of
+ * x and the table: H / 2 bytes per node instead of 4 H.  seg_add / node_graph (optional): row
+ * seg_add[node_graph[j]] (row stride ld_seg_add) is added to g_x[j] - the gradient of a sum pooled
+ * over each graph's nodes (src/modules/encoder.py:63-67), which is one row per graph, read where it
+ * is needed instead of being spread to [V, H] first.  Other arguments as above. */
+size_t psvae_gine_mask_bytes(int V, int H, int C);
+int psvae_gine_aggregate_fwd_bits(int V, int H, int C, const float *x, int ldx, const float *table,
+                                  const int32_t *row_ptr, const int32_t *col, const uint8_t *cls,
+                                  float *out, int ldo, void *mask_bits, void *stream);
+int psvae_gine_aggregate_bwd_bits(int V, int H, int C, const void *mask_bits, const float *g, int ldg,
+                                  const int32_t *t_row_ptr, const int32_t *t_col, const uint8_t *t_cls,
+                                  const float *add, int ldadd, const float *seg_add, int ld_seg_add,
+                                  const int32_t *node_graph, float *g_x, int ldgx, float *g_table,
+                                  int accumulate_table, void *workspace, size_t workspace_bytes, void *stream);
+
 /* psvae_gine_aggregate_bwd for callers that cannot allocate.  It has no counterpart in the
  * reference; it exists for code under HIP graph capture, tight serving loops and harnesses that
  * forbid hipMalloc.  Same arguments and results as psvae_gine_aggregate_bwd, without the
@@ -253,6 +283,15 @@ int psvae_gemm_f32_bits(int M, int N, int K, const float *A, int64_t sa_m, int64
                         const float *bias, int act, uint64_t *relu_bits, const uint64_t *gate_bits,
                         void *stream);
 
+/* out[v][n] = q[node_graph[v]][n] where the bit of (v, n) in gate_bits is set, else 0 (gate_bits: the
+ * sign-bit array of psvae_gemm_f32_bits over an [V, N] result).  The input gradient through a
+ * Linear + ReLU when the incoming gradient is the same row for every node of a graph (the last
+ * encoder iterate feeds only the per-graph pooled sum, src/modules/encoder.py:60-67): the product
+ * dY W runs once per graph, q = [graphs, N], and this kernel spreads and gates it.  N, ldq, ldo
+ * multiples of 4; 16-byte aligned rows. */
+int psvae_graph_rows_gated(int V, int N, const float *q, int ldq, const int32_t *node_graph,
+                           const uint64_t *gate_bits, float *out, int ldo, void *stream);
+
 /* out[n] (+)= sum_m x[m][n] * [mask[m][n] > 0] (mask optional, same ld as x);
  * deterministic two-stage reduction through `workspace`.  The bias gradient of a Linear. */
 size_t psvae_colsum_workspace_bytes(int M, int N);
@@ -273,11 +312,14 @@ int psvae_segment_sum_bwd(int B, int W, const float *g_out, int ldgo, const int3
  * Reparameterised latent (src/modules/vae_piece_decoder.py:56-63) after the two Linears:
  *     lv = -|lv_pre|;  z = mean + exp(lv/2) * eps;
  *     kl = -0.5 * sum(1 + lv - mean^2 - exp(lv)) / B
- * eps is supplied by the caller (the reference draws it with torch.randn_like).
+ * eps is supplied by the caller (the reference draws it with torch.randn_like).  The KL sum is
+ * taken in two stages in a fixed order through `workspace` (psvae_rsample_kl_workspace_bytes; 0 for
+ * a batch small enough for one workgroup).
  * Backward takes g_z [B,L] and the scalar g_kl (device pointer).
  * ---------------------------------------------------------------------------------- */
+size_t psvae_rsample_kl_workspace_bytes(int B, int L);
 int psvae_rsample_kl_fwd(int B, int L, const float *mean, const float *lv_pre, const float *eps,
-                         float *z, float *kl, void *stream);
+                         float *z, float *kl, void *workspace, size_t workspace_bytes, void *stream);
 int psvae_rsample_kl_bwd(int B, int L, const float *mean, const float *lv_pre, const float *eps,
                          const float *g_z, const float *g_kl, float *g_mean, float *g_lv_pre,
                          void *stream);

@@ -14,8 +14,13 @@
 // Molecules are small and contiguous in node order, so the neighbour rows a block gathers
 // are the rows it (or the adjacent block) streams anyway: they are served by L1/L2.
 #include <mutex>
+#include <type_traits>
 
 #include "common.h"
+
+#ifndef PSVAE_MASK16
+#define PSVAE_MASK16 uint16_t   // word of the message bits for C <= 4 (A/B builds: uint32_t)
+#endif
 
 namespace {
 
@@ -53,11 +58,31 @@ __device__ __forceinline__ bool stage_csr(StagedCsr &sc, int begin, int end, con
     return ok;
 }
 
-__global__ void gine_aggregate_fwd_kernel(int V, int cols, int slots, int nodes_per_block,
+// ReLU decisions of the messages a node SENDS, for the backward: the message of node j along an
+// edge of class k is ReLU(x[j] + table[k]), so its derivative depends on (j, k) only - 4 C bits per
+// float4 column of a node (bit 4 k + e: element e under class k), one 16-bit word for C <= 4 and one
+// 32-bit word for C <= 8, against the 16 bytes of the x values themselves.
+// (The table rows are read from memory where they are used - L1 hits - rather than held in registers per
+// thread: the register-held form was measured 25 % slower, these kernels live on occupancy.)
+template <int MAXC>
+__device__ __forceinline__ unsigned message_bits(float4 self, const float4 *__restrict__ table, int C, int cols, int c) {
+    unsigned w = 0;
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) {   // (rows beyond C: their bits are never read)
+        const float4 t = table[(k < C ? k : 0) * cols + c];
+        w |= (unsigned)(self.x + t.x > 0.f) << (4 * k) | (unsigned)(self.y + t.y > 0.f) << (4 * k + 1) |
+             (unsigned)(self.z + t.z > 0.f) << (4 * k + 2) | (unsigned)(self.w + t.w > 0.f) << (4 * k + 3);
+    }
+    return w;
+}
+
+template <int MAXC, typename WORD>   // WORD = void: no mask bits are written
+__global__ void gine_aggregate_fwd_kernel(int V, int C, int cols, int slots, int nodes_per_block,
                                           const float4 *__restrict__ x, int ldx4,
                                           const float4 *__restrict__ table,
                                           const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
-                                          const uint8_t *__restrict__ cls, float4 *__restrict__ out, int ldo4) {
+                                          const uint8_t *__restrict__ cls, float4 *__restrict__ out, int ldo4,
+                                          WORD *__restrict__ mask) {
     __shared__ StagedCsr sc;
     const int c = threadIdx.x % cols, slot = threadIdx.x / cols;
     const int begin = blockIdx.x * nodes_per_block;
@@ -89,13 +114,21 @@ __global__ void gine_aggregate_fwd_kernel(int V, int cols, int slots, int nodes_
                 if (e + u < e1) acc = add4(acc, relu_add(xj[u], t[u]));
         }
         out[(long long)i * ldo4 + c] = add4(acc, self);
+        // (the extra 2-byte store per lane costs the kernel ~15 %: 32-bit words, or collecting a block's words
+        // in LDS and writing them as one run, were measured no faster; the backward gains more than this loses)
+        if constexpr (!std::is_void<WORD>::value) mask[(long long)i * cols + c] = (WORD)message_bits<MAXC>(self, table, C, cols, c);
     }
 }
 
 // Backward over the CSR by SOURCE node.  Each thread keeps the table-gradient partial of
 // its column for every class; they are reduced over the slots of the block through LDS and
-// written as one [C,H] slab per block.
-template <int MAXC>
+// written as one [C,H] slab per block.  (Staging the indices in LDS as the forward does was
+// measured slower here: the index reads are L1 hits shared by the lanes of a row.)
+// WORD = void: the ReLU decisions are recomputed from x and the table; otherwise they are read from
+// the mask bits the forward left behind (x and table are not touched).  seg_add / node_graph
+// (optional): a per-GRAPH row added to every node of the graph (the gradient of a pooled sum over
+// the graph's nodes, which is the same row for all of them).
+template <int MAXC, typename WORD>
 __global__ void gine_aggregate_bwd_kernel(int V, int C, int cols, int slots, int nodes_per_block,
                                           const float4 *__restrict__ x, int ldx4,
                                           const float4 *__restrict__ table,
@@ -103,19 +136,27 @@ __global__ void gine_aggregate_bwd_kernel(int V, int C, int cols, int slots, int
                                           const int32_t *__restrict__ t_row_ptr,
                                           const int32_t *__restrict__ t_col, const uint8_t *__restrict__ t_cls,
                                           const float4 *__restrict__ add, int ldadd4, float4 *__restrict__ g_x,
-                                          int ldgx4, float4 *__restrict__ partial) {
+                                          int ldgx4, float4 *__restrict__ partial, const WORD *__restrict__ mask,
+                                          const float4 *__restrict__ seg_add, int ldsa4,
+                                          const int32_t *__restrict__ node_graph) {
+    constexpr bool BITS = !std::is_void<WORD>::value;
     extern __shared__ float4 sh[];   // [slots][C][cols]
     const int c = threadIdx.x % cols, slot = threadIdx.x / cols;
     const bool active = slot < slots;
     float4 gt[MAXC];
 #pragma unroll
     for (int k = 0; k < MAXC; ++k) gt[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int begin = blockIdx.x * nodes_per_block;
+    const int end = min(V, begin + nodes_per_block);
     if (active) {
-        const int begin = blockIdx.x * nodes_per_block;
-        const int end = min(V, begin + nodes_per_block);
         for (int j = begin + slot; j < end; j += slots) {
-            const float4 xj = x[(long long)j * ldx4 + c];
+            float4 xj = make_float4(0.f, 0.f, 0.f, 0.f);
+            unsigned bits = 0;
+            if constexpr (BITS) bits = mask[(long long)j * cols + c]; else xj = x[(long long)j * ldx4 + c];
             float4 acc = g[(long long)j * ldg4 + c];
+            float4 extra = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (seg_add != nullptr) extra = seg_add[(long long)node_graph[j] * ldsa4 + c];
+            if (add != nullptr) extra = add4(extra, add[(long long)j * ldadd4 + c]);
             const int e0 = t_row_ptr[j], e1 = t_row_ptr[j + 1];
             for (int eb = e0; eb < e1; eb += 4) {   // four destination rows in flight, as in the forward
                 int dst[4], kc[4];
@@ -128,27 +169,35 @@ __global__ void gine_aggregate_bwd_kernel(int V, int C, int cols, int slots, int
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     gd4[u] = g[(long long)dst[u] * ldg4 + c];
-                    t4[u] = table[kc[u] * cols + c];
+                    if constexpr (BITS) t4[u] = make_float4(0.f, 0.f, 0.f, 0.f); else t4[u] = table[kc[u] * cols + c];
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     if (eb + u >= e1) continue;
-                    const float4 gd = gd4[u], t = t4[u];
+                    const float4 gd = gd4[u];
                     const int k = kc[u];
                     float4 m;
-                    m.x = xj.x + t.x > 0.f ? gd.x : 0.f;
-                    m.y = xj.y + t.y > 0.f ? gd.y : 0.f;
-                    m.z = xj.z + t.z > 0.f ? gd.z : 0.f;
-                    m.w = xj.w + t.w > 0.f ? gd.w : 0.f;
+                    if constexpr (BITS) {
+                        const unsigned b = bits >> (4 * k);
+                        m.x = (b & 1u) ? gd.x : 0.f, m.y = (b & 2u) ? gd.y : 0.f;
+                        m.z = (b & 4u) ? gd.z : 0.f, m.w = (b & 8u) ? gd.w : 0.f;
+                    } else {
+                        const float4 t = t4[u];
+                        m.x = xj.x + t.x > 0.f ? gd.x : 0.f;
+                        m.y = xj.y + t.y > 0.f ? gd.y : 0.f;
+                        m.z = xj.z + t.z > 0.f ? gd.z : 0.f;
+                        m.w = xj.w + t.w > 0.f ? gd.w : 0.f;
+                    }
                     acc = add4(acc, m);
 #pragma unroll
                     for (int kk = 0; kk < MAXC; ++kk)
                         if (kk == k) gt[kk] = add4(gt[kk], m);
                 }
             }
-            if (add != nullptr) acc = add4(acc, add[(long long)j * ldadd4 + c]);
-            g_x[(long long)j * ldgx4 + c] = acc;
+            g_x[(long long)j * ldgx4 + c] = add4(acc, extra);
         }
+    }
+    if (active) {
 #pragma unroll
         for (int kk = 0; kk < MAXC; ++kk)
             if (kk < C) sh[(slot * C + kk) * cols + c] = gt[kk];
@@ -222,21 +271,52 @@ int check_common(const char *fn, int V, int H, int C, const void *x, int ldx) {
 
 }  // namespace
 
-extern "C" int psvae_gine_aggregate_fwd(int V, int H, int C, const float *x, int ldx, const float *table,
-                                        const int32_t *row_ptr, const int32_t *col, const uint8_t *cls,
-                                        float *out, int ldo, void *stream) {
-    int rc = check_common("psvae_gine_aggregate_fwd", V, H, C, x, ldx);
+static int aggregate_fwd_impl(const char *fn, int V, int H, int C, const float *x, int ldx, const float *table,
+                              const int32_t *row_ptr, const int32_t *col, const uint8_t *cls, float *out, int ldo,
+                              void *mask, hipStream_t s_) {
+    int rc = check_common(fn, V, H, C, x, ldx);
     if (rc) return rc;
     if (V == 0) return PSVAE_OK;
     PSVAE_REQUIRE(table && row_ptr && out && psvae_aligned16(table) && psvae_aligned16(out), PSVAE_EINVAL,
-                  "psvae_gine_aggregate_fwd: null or misaligned operand");
-    PSVAE_REQUIRE(ldo % 4 == 0 && ldo >= H, PSVAE_EINVAL, "psvae_gine_aggregate_fwd: bad ldo %d", ldo);
+                  "%s: null or misaligned operand", fn);
+    PSVAE_REQUIRE(ldo % 4 == 0 && ldo >= H, PSVAE_EINVAL, "%s: bad ldo %d", fn, ldo);
     const Shape s = shape_for(V, H, 0);
-    hipLaunchKernelGGL(gine_aggregate_fwd_kernel, dim3(s.blocks), dim3(s.threads), 0, (hipStream_t)stream, V,
-                       s.cols, s.slots, s.nodes_per_block, (const float4 *)x, ldx / 4, (const float4 *)table,
-                       row_ptr, col, cls, (float4 *)out, ldo / 4);
-    PSVAE_CHECK_LAUNCH("psvae_gine_aggregate_fwd");
+#define PSVAE_AGG_FWD(MAXC, WORD)                                                                                    \
+    hipLaunchKernelGGL((gine_aggregate_fwd_kernel<MAXC, WORD>), dim3(s.blocks), dim3(s.threads), 0, s_, V, C, s.cols,  \
+                       s.slots, s.nodes_per_block, (const float4 *)x, ldx / 4, (const float4 *)table, row_ptr, col,  \
+                       cls, (float4 *)out, ldo / 4, (WORD *)mask)
+    if (mask == nullptr) {
+        PSVAE_AGG_FWD(0, void);
+    } else if (C <= 4) {
+        PSVAE_AGG_FWD(4, PSVAE_MASK16);
+    } else {
+        PSVAE_AGG_FWD(8, uint32_t);
+    }
+#undef PSVAE_AGG_FWD
+    PSVAE_CHECK_LAUNCH(fn);
     return PSVAE_OK;
+}
+
+extern "C" int psvae_gine_aggregate_fwd(int V, int H, int C, const float *x, int ldx, const float *table,
+                                        const int32_t *row_ptr, const int32_t *col, const uint8_t *cls,
+                                        float *out, int ldo, void *stream) {
+    return aggregate_fwd_impl("psvae_gine_aggregate_fwd", V, H, C, x, ldx, table, row_ptr, col, cls, out, ldo, nullptr,
+                              (hipStream_t)stream);
+}
+
+extern "C" size_t psvae_gine_mask_bytes(int V, int H, int C) {
+    if (V <= 0 || H <= 0 || C <= 0) return 0;
+    return (size_t)V * (size_t)(H / 4) * (C <= 4 ? sizeof(PSVAE_MASK16) : sizeof(uint32_t));
+}
+
+extern "C" int psvae_gine_aggregate_fwd_bits(int V, int H, int C, const float *x, int ldx, const float *table,
+                                             const int32_t *row_ptr, const int32_t *col, const uint8_t *cls,
+                                             float *out, int ldo, void *mask_bits, void *stream) {
+    const char *fn = "psvae_gine_aggregate_fwd_bits";
+    PSVAE_REQUIRE(C <= 8, PSVAE_ETOOLARGE, "%s: at most 8 edge classes (C=%d)", fn, C);
+    PSVAE_REQUIRE(V <= 0 || (mask_bits != nullptr && (((uintptr_t)mask_bits) & (C <= 4 ? 1u : 3u)) == 0), PSVAE_EINVAL,
+                  "%s: mask_bits null or misaligned", fn);
+    return aggregate_fwd_impl(fn, V, H, C, x, ldx, table, row_ptr, col, cls, out, ldo, mask_bits, (hipStream_t)stream);
 }
 
 extern "C" size_t psvae_gine_aggregate_bwd_workspace_bytes(int V, int H, int C) {
@@ -250,22 +330,31 @@ extern "C" size_t psvae_gine_aggregate_bwd_workspace_bytes(int V, int H, int C) 
 static int aggregate_bwd_impl(const char *fn, int V, int H, int C, const float *x, int ldx, const float *table,
                               const float *g, int ldg, const int32_t *t_row_ptr, const int32_t *t_col,
                               const uint8_t *t_cls, const float *add, int ldadd, float *g_x, int ldgx,
-                              float *g_table, int accumulate_table, float *partial, hipStream_t s_) {
+                              float *g_table, int accumulate_table, float *partial, hipStream_t s_,
+                              const void *mask = nullptr, const float *seg_add = nullptr, int ldsa = 0,
+                              const int32_t *node_graph = nullptr) {
     if (V == 0) return accumulate_table ? PSVAE_OK : (int)hipMemsetAsync(g_table, 0, (size_t)C * H * sizeof(float), s_);
     PSVAE_REQUIRE(add == nullptr || (psvae_aligned16(add) && ldadd % 4 == 0 && ldadd >= H), PSVAE_EINVAL,
                   "%s: bad `add` operand", fn);
-    PSVAE_REQUIRE(table && t_row_ptr && g && g_x && psvae_aligned16(table) && psvae_aligned16(g) &&
+    PSVAE_REQUIRE((mask != nullptr || (table && psvae_aligned16(table))) && t_row_ptr && g && g_x && psvae_aligned16(g) &&
                       psvae_aligned16(g_x), PSVAE_EINVAL, "%s: null or misaligned operand", fn);
+    PSVAE_REQUIRE(seg_add == nullptr || (node_graph != nullptr && psvae_aligned16(seg_add) && ldsa % 4 == 0 && ldsa >= H),
+                  PSVAE_EINVAL, "%s: bad per-graph add operand", fn);
     PSVAE_REQUIRE(ldg % 4 == 0 && ldg >= H && ldgx % 4 == 0 && ldgx >= H, PSVAE_EINVAL, "%s: bad row stride", fn);
     const Shape s = shape_for(V, H, bwd_max_blocks());
     const size_t lds = (size_t)s.slots * C * s.cols * sizeof(float4);
     PSVAE_REQUIRE(lds <= 64 * 1024, PSVAE_ETOOLARGE, "%s: LDS need %zu", fn, lds);
-#define PSVAE_AGG_BWD(MAXC)                                                                                          \
-    hipLaunchKernelGGL(gine_aggregate_bwd_kernel<MAXC>, dim3(s.blocks), dim3(s.threads), lds, s_, V, C, s.cols,       \
+#define PSVAE_AGG_BWD(MAXC, WORD)                                                                                    \
+    hipLaunchKernelGGL((gine_aggregate_bwd_kernel<MAXC, WORD>), dim3(s.blocks), dim3(s.threads), lds, s_, V, C, s.cols, \
                        s.slots, s.nodes_per_block, (const float4 *)x, ldx / 4, (const float4 *)table,                \
                        (const float4 *)g, ldg / 4, t_row_ptr, t_col, t_cls, (const float4 *)add, ldadd / 4,          \
-                       (float4 *)g_x, ldgx / 4, (float4 *)partial)
-    if (C <= 4) PSVAE_AGG_BWD(4); else PSVAE_AGG_BWD(8);
+                       (float4 *)g_x, ldgx / 4, (float4 *)partial, (const WORD *)mask, (const float4 *)seg_add,      \
+                       ldsa / 4, node_graph)
+    if (mask == nullptr) {
+        if (C <= 4) PSVAE_AGG_BWD(4, void); else PSVAE_AGG_BWD(8, void);
+    } else {
+        if (C <= 4) PSVAE_AGG_BWD(4, PSVAE_MASK16); else PSVAE_AGG_BWD(8, uint32_t);
+    }
 #undef PSVAE_AGG_BWD
     PSVAE_CHECK_LAUNCH(fn);
     const int n_out = C * H;
@@ -290,6 +379,48 @@ extern "C" int psvae_gine_aggregate_bwd(int V, int H, int C, const float *x, int
                   PSVAE_EWORKSPACE, "%s: workspace too small", fn);
     return aggregate_bwd_impl(fn, V, H, C, x, ldx, table, g, ldg, t_row_ptr, t_col, t_cls, add, ldadd, g_x, ldgx,
                               g_table, accumulate_table, (float *)workspace, (hipStream_t)stream);
+}
+
+// psvae_gine_aggregate_bwd with an optional per-graph row added to every node of its graph.
+extern "C" int psvae_gine_aggregate_bwd_graph_add(int V, int H, int C, const float *x, int ldx, const float *table,
+                                                  const float *g, int ldg, const int32_t *t_row_ptr,
+                                                  const int32_t *t_col, const uint8_t *t_cls, const float *add, int ldadd,
+                                                  const float *seg_add, int ld_seg_add, const int32_t *node_graph,
+                                                  float *g_x, int ldgx, float *g_table, int accumulate_table,
+                                                  void *workspace, size_t workspace_bytes, void *stream) {
+    const char *fn = "psvae_gine_aggregate_bwd_graph_add";
+    int rc = check_common(fn, V, H, C, x, ldx);
+    if (rc) return rc;
+    PSVAE_REQUIRE(C <= 8, PSVAE_ETOOLARGE, "%s: at most 8 edge classes (C=%d)", fn, C);
+    PSVAE_REQUIRE(g_table != nullptr, PSVAE_EINVAL, "%s: g_table is null", fn);
+    PSVAE_REQUIRE(V == 0 || (workspace && psvae_aligned16(workspace) &&
+                             workspace_bytes >= psvae_gine_aggregate_bwd_workspace_bytes(V, H, C)),
+                  PSVAE_EWORKSPACE, "%s: workspace too small", fn);
+    return aggregate_bwd_impl(fn, V, H, C, x, ldx, table, g, ldg, t_row_ptr, t_col, t_cls, add, ldadd, g_x, ldgx, g_table,
+                              accumulate_table, (float *)workspace, (hipStream_t)stream, nullptr, seg_add, ld_seg_add,
+                              node_graph);
+}
+
+// The backward from the mask bits psvae_gine_aggregate_fwd_bits left behind (x and the table are not
+// read), with an optional per-graph row added to every node of its graph.
+extern "C" int psvae_gine_aggregate_bwd_bits(int V, int H, int C, const void *mask_bits, const float *g, int ldg,
+                                             const int32_t *t_row_ptr, const int32_t *t_col, const uint8_t *t_cls,
+                                             const float *add, int ldadd, const float *seg_add, int ld_seg_add,
+                                             const int32_t *node_graph, float *g_x, int ldgx, float *g_table,
+                                             int accumulate_table, void *workspace, size_t workspace_bytes,
+                                             void *stream) {
+    const char *fn = "psvae_gine_aggregate_bwd_bits";
+    PSVAE_REQUIRE(V >= 0 && H > 0 && C > 0 && H % 4 == 0 && H / 4 <= 1024, PSVAE_EINVAL, "%s: bad sizes V=%d H=%d C=%d", fn, V,
+                  H, C);
+    PSVAE_REQUIRE(C <= 8, PSVAE_ETOOLARGE, "%s: at most 8 edge classes (C=%d)", fn, C);
+    PSVAE_REQUIRE(g_table != nullptr && (V == 0 || (mask_bits != nullptr && (((uintptr_t)mask_bits) & (C <= 4 ? 1u : 3u)) == 0)),
+                  PSVAE_EINVAL, "%s: g_table null, or mask_bits null / misaligned", fn);
+    PSVAE_REQUIRE(V == 0 || (workspace && psvae_aligned16(workspace) &&
+                             workspace_bytes >= psvae_gine_aggregate_bwd_workspace_bytes(V, H, C)),
+                  PSVAE_EWORKSPACE, "%s: workspace too small", fn);
+    return aggregate_bwd_impl(fn, V, H, C, nullptr, H, nullptr, g, ldg, t_row_ptr, t_col, t_cls, add, ldadd, g_x, ldgx, g_table,
+                              accumulate_table, (float *)workspace, (hipStream_t)stream, mask_bits, seg_add, ld_seg_add,
+                              node_graph);
 }
 
 // ------------------------------------------------------------------------------------------

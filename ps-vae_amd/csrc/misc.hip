@@ -146,39 +146,89 @@ __global__ void segment_sum_bwd_kernel(int cols, const float4 *__restrict__ g_ou
     }
 }
 
-// ---------------------------------------------------------------- rsample + KL
-__global__ __launch_bounds__(1024) void rsample_kl_fwd_kernel(int B, int L, const float *__restrict__ mean,
-                                                              const float *__restrict__ lv_pre,
-                                                              const float *__restrict__ eps, float *__restrict__ z,
-                                                              float *__restrict__ kl) {
-    __shared__ float sh[1024];
-    const int total = B * L;
-    float s = 0.f;
-    constexpr int U = 24;  // loads in flight per thread: the single workgroup is latency-bound
-    for (int i0 = threadIdx.x; i0 < total; i0 += 1024 * U) {
-        float m[U], pre[U], e[U];
+// out[v] = q[node_graph[v]] gated by the sign bits of psvae_gemm_f32_bits over the [V, N] result
+// (the input gradient through a Linear + ReLU whose incoming gradient is the same row for every node
+// of a graph: the product runs once per graph, this kernel spreads and gates it).  A wave takes one
+// 32 x 32 tile of `out` with the lane mapping of the product's epilogue: lane l owns columns
+// 4 (l & 7) .. + 3 of rows (l >> 3) + 8 i, i = 0..3.
+__global__ __launch_bounds__(256) void graph_rows_gated_kernel(int V, int N, const float *__restrict__ q, int ldq,
+                                                               const int32_t *__restrict__ node_graph,
+                                                               const unsigned long long *__restrict__ bits, int ng,
+                                                               float *__restrict__ out, int ldo) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rg = blockIdx.x;
+    const int prow = lane >> 3, pc4 = (lane & 7) * 4;
+    int graph[4];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = min(i0 + 1024 * u, total - 1);
-            m[u] = mean[i], pre[u] = lv_pre[i], e[u] = eps[i];
-        }
+    for (int i = 0; i < 4; ++i) {
+        const int row = rg * 32 + prow + 8 * i;
+        graph[i] = row < V ? node_graph[row] : 0;
+    }
+    for (int cg = wave; cg < ng; cg += 4) {
+        const int col = cg * 32 + pc4;
+        if (col >= N) continue;
+        const unsigned long long *w = bits + ((long long)rg * ng + cg) * 16;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = i0 + 1024 * u;
-            if (i < total) {
-                const float lv = -fabsf(pre[u]);
-                s += 1.0f + lv - m[u] * m[u] - expf(lv);
-                z[i] = m[u] + expf(lv / 2) * e[u];
-            }
+        for (int i = 0; i < 4; ++i) {
+            const int row = rg * 32 + prow + 8 * i;
+            if (row >= V) continue;
+            float4 v = *reinterpret_cast<const float4 *>(q + (long long)graph[i] * ldq + col);
+            v.x = (w[4 * i] >> lane) & 1ull ? v.x : 0.f;
+            v.y = (w[4 * i + 1] >> lane) & 1ull ? v.y : 0.f;
+            v.z = (w[4 * i + 2] >> lane) & 1ull ? v.z : 0.f;
+            v.w = (w[4 * i + 3] >> lane) & 1ull ? v.w : 0.f;
+            *reinterpret_cast<float4 *>(out + (long long)row * ldo + col) = v;
         }
     }
+}
+
+// ---------------------------------------------------------------- rsample + KL
+// z and the KL sum in two stages: workgroups of 256 threads walk the B x L elements with a grid
+// stride and leave one partial sum each (a fixed tree inside the workgroup); one workgroup adds the
+// partials in a fixed tree.  A batch that fits one workgroup's walk writes kl directly.
+constexpr int RS_THREADS = 256, RS_MAX_BLOCKS = 256, RS_PER_THREAD = 4;
+
+__device__ __forceinline__ float rs_block_sum(float s, float *sh) {
     sh[threadIdx.x] = s;
     __syncthreads();
-    for (int d = 512; d > 0; d >>= 1) {
+    for (int d = RS_THREADS / 2; d > 0; d >>= 1) {
         if (threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d];
         __syncthreads();
     }
-    if (threadIdx.x == 0) *kl = -0.5f * sh[0] / (float)B;
+    return sh[0];
+}
+
+__global__ __launch_bounds__(RS_THREADS) void rsample_kl_fwd_kernel(int B, int L, const float *__restrict__ mean,
+                                                                    const float *__restrict__ lv_pre,
+                                                                    const float *__restrict__ eps, float *__restrict__ z,
+                                                                    float *__restrict__ part, float *__restrict__ kl) {
+    __shared__ float sh[RS_THREADS];
+    const int total = B * L;
+    float s = 0.f;
+    for (int i = blockIdx.x * RS_THREADS + threadIdx.x; i < total; i += gridDim.x * RS_THREADS) {
+        const float m = mean[i], lv = -fabsf(lv_pre[i]);
+        s += 1.0f + lv - m * m - expf(lv);
+        z[i] = m + expf(lv / 2) * eps[i];
+    }
+    s = rs_block_sum(s, sh);
+    if (threadIdx.x == 0) {
+        if (gridDim.x == 1)
+            *kl = -0.5f * s / (float)B;
+        else
+            part[blockIdx.x] = s;
+    }
+}
+
+__global__ __launch_bounds__(RS_THREADS) void rsample_kl_finish_kernel(int B, int n_part, const float *__restrict__ part,
+                                                                       float *__restrict__ kl) {
+    __shared__ float sh[RS_THREADS];
+    const float s = rs_block_sum(threadIdx.x < n_part ? part[threadIdx.x] : 0.f, sh);
+    if (threadIdx.x == 0) *kl = -0.5f * s / (float)B;
+}
+
+int rs_blocks(long long total) {
+    const long long b = (total + RS_THREADS * RS_PER_THREAD - 1) / (RS_THREADS * RS_PER_THREAD);
+    return (int)(b < 1 ? 1 : (b > RS_MAX_BLOCKS ? RS_MAX_BLOCKS : b));
 }
 
 __global__ void rsample_kl_bwd_kernel(int B, int L, const float *__restrict__ mean, const float *__restrict__ lv_pre,
@@ -762,12 +812,41 @@ extern "C" int psvae_segment_sum_bwd(int B, int W, const float *g_out, int ldgo,
     return PSVAE_OK;
 }
 
+extern "C" int psvae_graph_rows_gated(int V, int N, const float *q, int ldq, const int32_t *node_graph,
+                                      const uint64_t *gate_bits, float *out, int ldo, void *stream) {
+    const char *fn = "psvae_graph_rows_gated";
+    PSVAE_REQUIRE(V >= 0 && N > 0 && N % 4 == 0 && ldq % 4 == 0 && ldq >= N && ldo % 4 == 0 && ldo >= N, PSVAE_EINVAL,
+                  "%s: bad sizes V=%d N=%d ldq=%d ldo=%d", fn, V, N, ldq, ldo);
+    if (V == 0) return PSVAE_OK;
+    PSVAE_REQUIRE(q && node_graph && gate_bits && out && psvae_aligned16(q) && psvae_aligned16(out), PSVAE_EINVAL,
+                  "%s: null or misaligned operand", fn);
+    hipLaunchKernelGGL(graph_rows_gated_kernel, dim3(psvae_cdiv(V, 32)), dim3(256), 0, (hipStream_t)stream, V, N, q, ldq,
+                       node_graph, (const unsigned long long *)gate_bits, psvae_cdiv(N, 32), out, ldo);
+    PSVAE_CHECK_LAUNCH(fn);
+    return PSVAE_OK;
+}
+
+extern "C" size_t psvae_rsample_kl_workspace_bytes(int B, int L) {
+    if (B <= 0 || L <= 0) return 0;
+    const int nb = rs_blocks((long long)B * L);
+    return nb <= 1 ? 0 : (size_t)nb * sizeof(float);
+}
+
 extern "C" int psvae_rsample_kl_fwd(int B, int L, const float *mean, const float *lv_pre, const float *eps, float *z,
-                                    float *kl, void *stream) {
+                                    float *kl, void *workspace, size_t workspace_bytes, void *stream) {
     PSVAE_REQUIRE(B > 0 && L > 0 && (long long)B * L < (1ll << 31), PSVAE_EINVAL, "psvae_rsample_kl_fwd: bad sizes");
     PSVAE_REQUIRE(mean && lv_pre && eps && z && kl, PSVAE_EINVAL, "psvae_rsample_kl_fwd: null pointer");
-    hipLaunchKernelGGL(rsample_kl_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, B, L, mean, lv_pre, eps, z, kl);
+    const int nb = rs_blocks((long long)B * L);
+    PSVAE_REQUIRE(nb == 1 || (workspace != nullptr && workspace_bytes >= (size_t)nb * sizeof(float)), PSVAE_EWORKSPACE,
+                  "psvae_rsample_kl_fwd: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(rsample_kl_fwd_kernel, dim3(nb), dim3(RS_THREADS), 0, s, B, L, mean, lv_pre, eps, z, (float *)workspace,
+                       kl);
     PSVAE_CHECK_LAUNCH("psvae_rsample_kl_fwd");
+    if (nb > 1) {
+        hipLaunchKernelGGL(rsample_kl_finish_kernel, dim3(1), dim3(RS_THREADS), 0, s, B, nb, (const float *)workspace, kl);
+        PSVAE_CHECK_LAUNCH("psvae_rsample_kl_fwd (finish)");
+    }
     return PSVAE_OK;
 }
 

@@ -134,8 +134,10 @@ void gine_aggregate_fwd(const Tensor &x, const Tensor &table, const Tensor &row_
 }
 
 void gine_aggregate_bwd(const Tensor &x, const Tensor &table, const Tensor &g, const Tensor &t_row_ptr, const Tensor &t_col,
-                        const Tensor &t_cls, const OptTensor &add, Tensor g_x, Tensor g_table, bool accumulate_table) {
-    PSVAE_ON_DEVICE("psvae::gine_aggregate_bwd", p(x), p(table), p(g), p(t_row_ptr), p(t_col), p(t_cls), p(add), p(g_x), p(g_table));
+                        const Tensor &t_cls, const OptTensor &add, const OptTensor &seg_add, const OptTensor &node_graph,
+                        Tensor g_x, Tensor g_table, bool accumulate_table) {
+    PSVAE_ON_DEVICE("psvae::gine_aggregate_bwd", p(x), p(table), p(g), p(t_row_ptr), p(t_col), p(t_cls), p(add), p(seg_add),
+                    p(node_graph), p(g_x), p(g_table));
     const char *fn = "psvae_gine_aggregate_bwd";
     const int V = (int)x.size(0), H = (int)x.size(1), C = (int)table.size(0);
     void *s = cur_stream(x);
@@ -144,11 +146,76 @@ void gine_aggregate_bwd(const Tensor &x, const Tensor &table, const Tensor &g, c
     Tensor hold;
     if (nbytes) hold = workspace(nbytes, x, s), ws = hold.data_ptr();
     const bool has_add = add.has_value() && add->defined();
-    check(psvae_gine_aggregate_bwd(V, H, C, f32(x, fn), (int)row_stride(x, fn), f32(table, fn), f32(g, fn),
-                                   (int)row_stride(g, fn), i32(t_row_ptr, fn), i32(t_col, fn), u8(t_cls, fn),
-                                   f32(add, fn), has_add ? (int)row_stride(*add, fn) : H, f32_mut(g_x, fn),
-                                   (int)row_stride(g_x, fn), f32_mut(g_table, fn), accumulate_table ? 1 : 0, ws, nbytes, s),
+    const bool has_seg = seg_add.has_value() && seg_add->defined();
+    TORCH_CHECK(!has_seg || (node_graph.has_value() && node_graph->defined() && node_graph->numel() == V), fn,
+                ": seg_add needs node_graph [V]");
+    check(psvae_gine_aggregate_bwd_graph_add(V, H, C, f32(x, fn), (int)row_stride(x, fn), f32(table, fn), f32(g, fn),
+                                             (int)row_stride(g, fn), i32(t_row_ptr, fn), i32(t_col, fn), u8(t_cls, fn),
+                                             f32(add, fn), has_add ? (int)row_stride(*add, fn) : H, f32(seg_add, fn),
+                                             has_seg ? (int)row_stride(*seg_add, fn) : H,
+                                             has_seg ? i32(*node_graph, fn) : nullptr, f32_mut(g_x, fn),
+                                             (int)row_stride(g_x, fn), f32_mut(g_table, fn), accumulate_table ? 1 : 0, ws, nbytes,
+                                             s),
           fn);
+}
+
+// raw storage of the mask-bit array: one word per float4 column of a node, of the width the library reports
+void *mask_ptr(const Tensor &mask, int64_t V, int64_t H, int64_t C, const char *fn) {
+    const int64_t words = V * (H / 4);
+    const bool narrow = words > 0 && psvae_gine_mask_bytes((int)V, (int)H, (int)C) == (size_t)words * 2;
+    const auto want = narrow ? at::kShort : at::kInt;
+    TORCH_CHECK(mask.is_cuda() && (words == 0 || mask.scalar_type() == want) && mask.is_contiguous() && mask.numel() >= words, fn,
+                ": mask bits are a contiguous ", (narrow ? "int16" : "int32"), " GPU tensor of at least V * H / 4 words");
+    return mask.data_ptr();
+}
+
+void gine_aggregate_fwd_bits(const Tensor &x, const Tensor &table, const Tensor &row_ptr, const Tensor &col, const Tensor &cls,
+                             Tensor out, Tensor mask) {
+    PSVAE_ON_DEVICE("psvae::gine_aggregate_fwd_bits", p(x), p(table), p(row_ptr), p(col), p(cls), p(out), p(mask));
+    const char *fn = "psvae_gine_aggregate_fwd_bits";
+    const int V = (int)x.size(0), H = (int)x.size(1), C = (int)table.size(0);
+    check(psvae_gine_aggregate_fwd_bits(V, H, C, f32(x, fn), (int)row_stride(x, fn), f32(table, fn), i32(row_ptr, fn), i32(col, fn),
+                                        u8(cls, fn), f32_mut(out, fn), (int)row_stride(out, fn), mask_ptr(mask, V, H, C, fn),
+                                        cur_stream(x)),
+          fn);
+}
+
+void gine_aggregate_bwd_bits(const Tensor &mask, int64_t C, const Tensor &g, const Tensor &t_row_ptr, const Tensor &t_col,
+                             const Tensor &t_cls, const OptTensor &add, const OptTensor &seg_add, const OptTensor &node_graph,
+                             Tensor g_x, Tensor g_table, bool accumulate_table) {
+    PSVAE_ON_DEVICE("psvae::gine_aggregate_bwd_bits", p(mask), p(g), p(t_row_ptr), p(t_col), p(t_cls), p(add), p(seg_add),
+                    p(node_graph), p(g_x), p(g_table));
+    const char *fn = "psvae_gine_aggregate_bwd_bits";
+    const int V = (int)g.size(0), H = (int)g.size(1);
+    TORCH_CHECK(g_table.size(0) == C && g_table.size(1) == H && g_table.is_contiguous(), fn, ": g_table must be [C, H]");
+    void *s = cur_stream(g);
+    const size_t nbytes = psvae_gine_aggregate_bwd_workspace_bytes(V, H, (int)C);
+    void *ws = nullptr;
+    Tensor hold;
+    if (nbytes) hold = workspace(nbytes, g, s), ws = hold.data_ptr();
+    const bool has_add = add.has_value() && add->defined();
+    const bool has_seg = seg_add.has_value() && seg_add->defined();
+    TORCH_CHECK(!has_seg || (node_graph.has_value() && node_graph->defined() && node_graph->numel() == V), fn,
+                ": seg_add needs node_graph [V]");
+    check(psvae_gine_aggregate_bwd_bits(V, H, (int)C, mask_ptr(mask, V, H, C, fn), f32(g, fn), (int)row_stride(g, fn),
+                                        i32(t_row_ptr, fn), i32(t_col, fn), u8(t_cls, fn), f32(add, fn),
+                                        has_add ? (int)row_stride(*add, fn) : H, f32(seg_add, fn),
+                                        has_seg ? (int)row_stride(*seg_add, fn) : H, has_seg ? i32(*node_graph, fn) : nullptr,
+                                        f32_mut(g_x, fn), (int)row_stride(g_x, fn), f32_mut(g_table, fn),
+                                        accumulate_table ? 1 : 0, ws, nbytes, s),
+          fn);
+}
+
+void graph_rows_gated(const Tensor &q, const Tensor &node_graph, const Tensor &gate_bits, Tensor out) {
+    PSVAE_ON_DEVICE("psvae::graph_rows_gated", p(q), p(node_graph), p(gate_bits), p(out));
+    const char *fn = "psvae_graph_rows_gated";
+    const int V = (int)out.size(0), N = (int)out.size(1);
+    TORCH_CHECK(q.dim() == 2 && q.size(1) == N && node_graph.numel() == V, fn, ": q must be [graphs, N], node_graph [V]");
+    TORCH_CHECK(gate_bits.is_cuda() && gate_bits.scalar_type() == at::kLong && gate_bits.is_contiguous() &&
+                    (size_t)gate_bits.numel() >= psvae_gemm_f32_bits_words(V, N), fn, ": gate_bits too short");
+    check(psvae_graph_rows_gated(V, N, f32(q, fn), (int)row_stride(q, fn), i32(node_graph, fn),
+                                 reinterpret_cast<const uint64_t *>(gate_bits.const_data_ptr<int64_t>()), f32_mut(out, fn),
+                                 (int)row_stride(out, fn), cur_stream(out)), fn);
 }
 
 void pair_combine_fwd(const Tensor &a, const Tensor &b, const Tensor &c, const Tensor &src, const Tensor &dst,
@@ -227,8 +294,13 @@ void segment_sum_bwd(const Tensor &g_out, const Tensor &seg_begin, const Tensor 
 void rsample_kl_fwd(const Tensor &mean, const Tensor &lv_pre, const Tensor &eps, Tensor z, Tensor kl) {
     PSVAE_ON_DEVICE("psvae::rsample_kl_fwd", p(mean), p(lv_pre), p(eps), p(z), p(kl));
     const char *fn = "psvae_rsample_kl_fwd";
+    void *s = cur_stream(z);
+    const size_t nbytes = psvae_rsample_kl_workspace_bytes((int)mean.size(0), (int)mean.size(1));
+    void *ws = nullptr;
+    Tensor hold;
+    if (nbytes) hold = workspace(nbytes, z, s), ws = hold.data_ptr();
     check(psvae_rsample_kl_fwd((int)mean.size(0), (int)mean.size(1), f32c(mean, fn), f32c(lv_pre, fn), f32c(eps, fn),
-                               const_cast<float *>(f32c(z, fn)), f32_mut(kl, fn), cur_stream(z)), fn);
+                               const_cast<float *>(f32c(z, fn)), f32_mut(kl, fn), ws, nbytes, s), fn);
 }
 
 void rsample_kl_bwd(const Tensor &mean, const Tensor &lv_pre, const Tensor &eps, const OptTensor &g_z, const OptTensor &g_kl,
@@ -390,7 +462,14 @@ TORCH_LIBRARY(psvae, m) {
     m.def("gine_aggregate_fwd(Tensor x, Tensor table, Tensor row_ptr, Tensor col, Tensor cls, Tensor(a!) out) -> ()",
           &gine_aggregate_fwd);
     m.def("gine_aggregate_bwd(Tensor x, Tensor table, Tensor g, Tensor t_row_ptr, Tensor t_col, Tensor t_cls, Tensor? add, "
-          "Tensor(a!) g_x, Tensor(b!) g_table, bool accumulate_table) -> ()", &gine_aggregate_bwd);
+          "Tensor? seg_add, Tensor? node_graph, Tensor(a!) g_x, Tensor(b!) g_table, bool accumulate_table) -> ()",
+          &gine_aggregate_bwd);
+    m.def("gine_aggregate_fwd_bits(Tensor x, Tensor table, Tensor row_ptr, Tensor col, Tensor cls, Tensor(a!) out, "
+          "Tensor(b!) mask) -> ()", &gine_aggregate_fwd_bits);
+    m.def("gine_aggregate_bwd_bits(Tensor mask, int C, Tensor g, Tensor t_row_ptr, Tensor t_col, Tensor t_cls, Tensor? add, "
+          "Tensor? seg_add, Tensor? node_graph, Tensor(a!) g_x, Tensor(b!) g_table, bool accumulate_table) -> ()",
+          &gine_aggregate_bwd_bits);
+    m.def("graph_rows_gated(Tensor q, Tensor node_graph, Tensor gate_bits, Tensor(a!) out) -> ()", &graph_rows_gated);
     m.def("pair_combine_fwd(Tensor a, Tensor b, Tensor c, Tensor src, Tensor dst, Tensor graph, bool relu, Tensor(a!) out) -> ()",
           &pair_combine_fwd);
     m.def("pair_combine_bwd(Tensor g_out, Tensor? out, bool relu, Tensor src, Tensor dst, Tensor pair_ptr, Tensor node_begin, "

@@ -39,6 +39,13 @@ _SIGNATURES = {
     'psvae_keyed_row_sum_workspace_bytes': (_c_size, [_c_ll, _c_int, _c_int, _c_int]),
     'psvae_keyed_row_sum': (_c_int, [_c_int, _c_int, _c_ll, _c_int, _p, _c_int, _p, _p, _p, _p, _c_int, _p, _c_size, _p]),
     'psvae_gine_aggregate_fwd': (_c_int, [_c_int, _c_int, _c_int, _p, _c_int, _p, _p, _p, _p, _p, _c_int, _p]),
+    'psvae_gine_mask_bytes': (_c_size, [_c_int, _c_int, _c_int]),
+    'psvae_gine_aggregate_fwd_bits': (_c_int, [_c_int, _c_int, _c_int, _p, _c_int, _p, _p, _p, _p, _p, _c_int, _p, _p]),
+    'psvae_gine_aggregate_bwd_bits': (_c_int, [_c_int, _c_int, _c_int, _p, _p, _c_int, _p, _p, _p, _p, _c_int, _p, _c_int, _p,
+                                               _p, _c_int, _p, _c_int, _p, _c_size, _p]),
+    'psvae_gine_aggregate_bwd_graph_add': (_c_int, [_c_int, _c_int, _c_int, _p, _c_int, _p, _p, _c_int, _p, _p, _p, _p, _c_int,
+                                                    _p, _c_int, _p, _p, _c_int, _p, _c_int, _p, _c_size, _p]),
+    'psvae_graph_rows_gated': (_c_int, [_c_int, _c_int, _p, _c_int, _p, _p, _p, _c_int, _p]),
     'psvae_gine_aggregate_bwd_workspace_bytes': (_c_size, [_c_int, _c_int, _c_int]),
     'psvae_gine_aggregate_bwd': (_c_int, [_c_int, _c_int, _c_int, _p, _c_int, _p, _p, _c_int, _p, _p, _p, _p,
                                           _c_int, _p, _c_int, _p, _c_int, _p, _c_size, _p]),
@@ -55,7 +62,8 @@ _SIGNATURES = {
     'psvae_colsum_f32': (_c_int, [_c_int, _c_int, _p, _p, _c_i64, _p, _c_int, _p, _c_size, _p]),
     'psvae_segment_sum_fwd': (_c_int, [_c_int, _c_int, _p, _c_int, _p, _p, _p, _c_int, _p]),
     'psvae_segment_sum_bwd': (_c_int, [_c_int, _c_int, _p, _c_int, _p, _p, _p, _c_int, _p]),
-    'psvae_rsample_kl_fwd': (_c_int, [_c_int, _c_int, _p, _p, _p, _p, _p, _p]),
+    'psvae_rsample_kl_workspace_bytes': (_c_size, [_c_int, _c_int]),
+    'psvae_rsample_kl_fwd': (_c_int, [_c_int, _c_int, _p, _p, _p, _p, _p, _p, _c_size, _p]),
     'psvae_rsample_kl_bwd': (_c_int, [_c_int, _c_int, _p, _p, _p, _p, _p, _p, _p, _p]),
     'psvae_gru_cell_fwd': (_c_int, [_c_int, _c_int, _p, _p, _p, _p, _p, _p]),
     'psvae_gru_cell_bwd': (_c_int, [_c_int, _c_int, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
@@ -336,11 +344,49 @@ def gine_aggregate_fwd(x, table, row_ptr, col, cls, out):
         ops().gine_aggregate_fwd(x, table, row_ptr, col, cls, out)
 
 
-def gine_aggregate_bwd(x, table, g, t_row_ptr, t_col, t_cls, g_x, g_table, add=None, accumulate_table=False):
+def gine_aggregate_bwd(x, table, g, t_row_ptr, t_col, t_cls, g_x, g_table, add=None, accumulate_table=False, seg_add=None,
+                       node_graph=None):
+    """seg_add [graphs, H] / node_graph [V]: a per-graph row added to every node of the graph
+    (psvae_gine_aggregate_bwd_graph_add)."""
     V, H = x.shape
     _count()
     with _Prof('gine_aggregate_bwd_kernel', aggregate_bytes(V, t_col.numel(), H, backward=True)):
-        ops().gine_aggregate_bwd(x, table, g, t_row_ptr, t_col, t_cls, add, g_x, g_table, accumulate_table)
+        ops().gine_aggregate_bwd(x, table, g, t_row_ptr, t_col, t_cls, add, seg_add, node_graph, g_x, g_table,
+                                 accumulate_table)
+
+
+def gine_mask_words(V, H, C):
+    """(number of words, dtype) of the mask-bit array of gine_aggregate_fwd_bits: one word per float4
+    column of a node, of the width psvae_gine_mask_bytes reports (int16 or int32 storage)."""
+    words = V * (H // 4)
+    width = lib().psvae_gine_mask_bytes(max(V, 1), H, C) // (max(V, 1) * (H // 4))
+    return words, (torch.int16 if width == 2 else torch.int32)
+
+
+def gine_aggregate_fwd_bits(x, table, row_ptr, col, cls, out, mask):
+    """psvae_gine_aggregate_fwd_bits: the aggregation, leaving the ReLU decisions of the messages behind
+    as bits in `mask` (gine_mask_words)."""
+    V, H = x.shape
+    _count()
+    with _Prof('gine_aggregate_fwd_kernel', aggregate_bytes(V, col.numel(), H)):
+        ops().gine_aggregate_fwd_bits(x, table, row_ptr, col, cls, out, mask)
+
+
+def gine_aggregate_bwd_bits(mask, C, g, t_row_ptr, t_col, t_cls, g_x, g_table, add=None, seg_add=None, node_graph=None,
+                            accumulate_table=False):
+    """psvae_gine_aggregate_bwd_bits: the backward from the mask bits (x and the table are not read);
+    seg_add [graphs, H] / node_graph [V]: a per-graph row added to every node of the graph."""
+    V, H = g.shape
+    _count()
+    with _Prof('gine_aggregate_bwd_kernel', aggregate_bytes(V, t_col.numel(), H, backward=True)):
+        ops().gine_aggregate_bwd_bits(mask, C, g, t_row_ptr, t_col, t_cls, add, seg_add, node_graph, g_x, g_table,
+                                      accumulate_table)
+
+
+def graph_rows_gated(q, node_graph, gate_bits, out):
+    """out[v] = q[node_graph[v]] where the sign bit of (v, n) is set, else 0 (psvae_graph_rows_gated)."""
+    _count()
+    ops().graph_rows_gated(q, node_graph, gate_bits, out)
 
 
 def gine_aggregate_bwd_noalloc(x, table, g, t_row_ptr, t_col, t_cls, g_x, g_table, add=None, accumulate_table=False):

@@ -77,6 +77,23 @@ class Encoder(nn.Module):
             all_x.append(x)
         return x, (torch.cat(all_x, dim=-1) if want_all else None)
 
+    def embed_graph_of_nodes(self, x, csr, segments):
+        """embed_graph(embed_node(x)[1]) (src/modules/encoder.py:53-69) for batches in the compact
+        layout: with the reference's conv MLP the sum over each graph's nodes is taken inside the
+        encoder's autograd node, whose backward then works from one gradient row per graph."""
+        mlp = self.conv.nn.seq
+        fused = (isinstance(mlp, nn.Sequential) and len(mlp) == 3 and isinstance(mlp[1], nn.ReLU)
+                 and mlp[0].bias is not None and mlp[2].bias is not None and self.node_trans.bias is not None)
+        hidden = self.node_trans.out_features
+        if (fused and hidden % 4 == 0 and isinstance(x, ops.EmbeddedIds) and isinstance(csr, ops.Csr)
+                and isinstance(segments, ops.Segments) and segments.covers_all_rows):
+            x0 = ops.embed_trans(x, self.node_trans.weight, self.node_trans.bias)
+            pooled = ops.gine_encoder(x0, None, None, self.edge_table(), mlp[0].weight, mlp[0].bias,
+                                      mlp[2].weight, mlp[2].bias, csr, self.t, False, segments)
+            return run_linear(self.linear, pooled)
+        _, all_x = self.embed_node(x, csr)
+        return self.embed_graph(all_x, segments)
+
     def embed_graph(self, all_x, graph_ids, node_mask=None):
         if isinstance(graph_ids, ops.Segments):
             segs = graph_ids

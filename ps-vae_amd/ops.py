@@ -10,6 +10,11 @@ from . import hip
 # (used to count ReLU outputs whose sign differs from a float64 evaluation).
 RELU_TRACE = None
 
+# Whether the fused encoder node carries the ReLU decisions of the messages as bits (left behind by
+# the aggregation forward, read by its backward instead of the input rows).
+import os as _os
+MESSAGE_BITS = _os.environ.get('PSVAE_MESSAGE_BITS', '1') != '0'
+
 
 # ------------------------------------------------------------------------ index containers
 class Csr:
@@ -65,6 +70,22 @@ class Segments:
     @classmethod
     def from_offsets(cls, node_off):
         return cls(node_off[:-1], node_off[1:], True)
+
+    def counts(self):
+        """Rows per graph, float32 [B] (made once)."""
+        if getattr(self, '_counts', None) is None:
+            self._counts = (self.end - self.begin).to(torch.float32)
+        return self._counts
+
+    def node_graph(self, rows):
+        """Graph of every row, int32 [rows] (made once; segments that cover all `rows` rows only)."""
+        if not self.covers_all_rows:
+            raise ValueError('node_graph needs segments that cover all rows')
+        if getattr(self, '_node_graph', None) is None:
+            n = (self.end - self.begin).to(torch.int64)
+            ids = torch.arange(self.num_graphs, dtype=torch.int32, device=self.begin.device)
+            self._node_graph = torch.repeat_interleave(ids, n, output_size=rows)    # (the size given: no host stop)
+        return self._node_graph
 
 
 class PairList:
@@ -196,10 +217,21 @@ class _GineEncoder(Function):
     applied in the epilogue of the product that produces the gradient, the slot gradient of an iterate is added
     inside the aggregation backward, and the gradients of the shared conv weights are ONE
     product each over the t iterations stacked along K (K = t*V) with the bias gradient
-    taken from the same pass."""
+    taken from the same pass.  ReLU decisions travel as bits: those of every layer's first Linear
+    (one bit per element, left behind by the product's epilogue) and those of the messages (4 C bits
+    per float4 column of a node, left behind by the aggregation), so the backward re-reads neither
+    the hidden activations nor the aggregation's input rows.
+
+    pool (Segments covering all rows): the node also takes embed_graph's sum over each graph's
+    nodes (src/modules/encoder.py:63-67) and returns the pooled [B, t*H] instead of [V, t*H].
+    Its backward then starts from ONE gradient row per graph and never spreads it to the nodes:
+    the aggregation backward adds the graph's row where it writes a node's gradient; the last
+    iterate, which feeds nothing but the pool, gets its input-gradient product once per graph
+    (then spread and gated per node), and its weight-gradient block is a product over the graphs
+    against the per-graph sums of the hidden rows."""
 
     @staticmethod
-    def forward(ctx, x_in, w0, b0, table, w1, b1, w2, b2, csr, t, only_last=False):
+    def forward(ctx, x_in, w0, b0, table, w1, b1, w2, b2, csr, t, only_last=False, pool=None):
         """w0 None: x_in [V,H] already is node_trans' output (see embed_trans).
         only_last: return the last iterate alone (its slot of the internal buffer) - the caller that
         uses nothing else then gets a [V,H] gradient instead of a [V, t*H] one that is zero in t-1
@@ -207,6 +239,7 @@ class _GineEncoder(Function):
         x_in = _rows2d(x_in)
         V, Din = x_in.shape
         H = w1.shape[1]
+        C = table.shape[0]
         dev = x_in.device
         w1, w2, table = w1.contiguous(), w2.contiguous(), table.contiguous()
         all_x = torch.empty(V, t * H, dtype=torch.float32, device=dev)
@@ -221,11 +254,21 @@ class _GineEncoder(Function):
             hip.gemm(V, H, Din, x_in, _ld(x_in), 1, w0, 1, Din, x0, H, bias=b0)
         # The ReLU decisions of every layer's first Linear as bits (V H / 8 bytes per layer): the
         # backward gates its gradient with them instead of re-reading h
-        use_bits = V >= 32 and any(ctx.needs_input_grad)
+        grad = any(ctx.needs_input_grad)
+        use_bits = V >= 32 and grad
         bits = torch.empty(t, hip.gemm_bits_words(V, H), dtype=torch.int64, device=dev) if use_bits else None
+        # and those of the messages every node sends (H / 2 bytes per node and layer for C <= 4)
+        use_masks = grad and C <= 8 and V > 0 and MESSAGE_BITS
+        masks = None
+        if use_masks:
+            words, wtype = hip.gine_mask_words(V, H, C)
+            masks = torch.empty(t, words, dtype=wtype, device=dev)
         prev = x0
         for i in range(t):
-            hip.gine_aggregate_fwd(prev, table, csr.row_ptr, csr.col, csr.cls, a[i])
+            if use_masks:
+                hip.gine_aggregate_fwd_bits(prev, table, csr.row_ptr, csr.col, csr.cls, a[i], masks[i])
+            else:
+                hip.gine_aggregate_fwd(prev, table, csr.row_ptr, csr.col, csr.cls, a[i])
             if use_bits:
                 hip.gemm_bits(V, H, H, a[i], H, 1, w1, 1, H, h[i], H, bias=b1, relu=True, relu_bits=bits[i])
             else:
@@ -235,45 +278,79 @@ class _GineEncoder(Function):
             slot = all_x[:, i * H:(i + 1) * H]
             hip.gemm(V, H, H, h[i], H, 1, w2, 1, H, slot, t * H, bias=b2)
             prev = slot
-        ctx.csr, ctx.t, ctx.only_last = csr, t, only_last
-        ctx.save_for_backward(x_in, w0, table, w1, w2, x0, all_x, a, h, bits)
+        ctx.csr, ctx.t, ctx.only_last, ctx.pool = csr, t, only_last, pool
+        ctx.shape = (V, H, C)
+        # with the message bits the backward needs neither x0 nor the iterates
+        ctx.save_for_backward(x_in, w0, table, w1, w2, None if use_masks else x0, None if use_masks else all_x, a, h, bits,
+                              masks)
+        if pool is not None:
+            pooled = torch.empty(pool.num_graphs, t * H, dtype=torch.float32, device=dev)
+            hip.segment_sum_fwd(all_x, pool.begin, pool.end, pooled)
+            return pooled
         return all_x[:, (t - 1) * H:] if only_last else all_x
 
     @staticmethod
     def backward(ctx, g_all):
-        x_in, w0, table, w1, w2, x0, all_x, a, h, bits = ctx.saved_tensors
-        csr, t = ctx.csr, ctx.t
-        V, H = x0.shape
-        dev = x0.device
+        x_in, w0, table, w1, w2, x0, all_x, a, h, bits, masks = ctx.saved_tensors
+        csr, t, pool = ctx.csr, ctx.t, ctx.pool
+        V, H, C = ctx.shape
+        dev = a.device
         only_last = ctx.only_last      # then g_all is the gradient of the last iterate alone, [V,H]
         if g_all.dtype != torch.float32:
             g_all = g_all.float()
         if not g_all.is_contiguous():
             g_all = g_all.contiguous()
         f32 = dict(dtype=torch.float32, device=dev)
+        g_pool = None
+        if pool is not None:
+            if bits is not None:
+                g_pool = g_all                         # [B, t*H]: one row per graph, kept that way
+            else:                                      # small batches / wide class sets: spread it to the nodes
+                spread = torch.empty(V, t * H, **f32)
+                hip.segment_sum_bwd(g_all, pool.begin, pool.end, spread)
+                g_all = spread
         # dL/d x_i (output of layer i) for i < t-1, stacked for the dW2 product; the gradient of the
         # last iterate is read where it arrives (a [V,H] block of g_all): no copy into the stack
-        last = g_all if only_last else g_all[:, (t - 1) * H:]
+        last = None if g_pool is not None else (g_all if only_last else g_all[:, (t - 1) * H:])
         gx = torch.empty(max(t - 1, 1), V, H, **f32)
         gh = torch.empty(t, V, H, **f32)      # dL/d (pre-activation of h_i): gated as it is produced
         ga = torch.empty(V, H, **f32)
         g_x0 = torch.empty(V, H, **f32)
         g_table = torch.empty_like(table)
-        for i in range(t - 1, -1, -1):
-            g_i = last if i == t - 1 else gx[i]
-            if bits is not None:                                                # through the last Linear + ReLU
-                hip.gemm_bits(V, H, H, g_i, _ld(g_i), 1, w2, H, 1, gh[i], H, gate_bits=bits[i])
+        node_graph = pool.node_graph(V) if g_pool is not None else None
+
+        def aggregate_bwd(i, x_prev, out, add, seg_add, first):
+            if masks is not None:
+                hip.gine_aggregate_bwd_bits(masks[i], C, ga, csr.t_row_ptr, csr.t_col, csr.t_cls, out, g_table, add=add,
+                                            seg_add=seg_add, node_graph=node_graph if seg_add is not None else None,
+                                            accumulate_table=not first)
             else:
-                hip.gemm(V, H, H, g_i, _ld(g_i), 1, w2, H, 1, gh[i], H, cmask=h[i])
+                hip.gine_aggregate_bwd(x_prev, table, ga, csr.t_row_ptr, csr.t_col, csr.t_cls, out, g_table, add=add,
+                                       accumulate_table=not first, seg_add=seg_add,
+                                       node_graph=node_graph if seg_add is not None else None)
+
+        for i in range(t - 1, -1, -1):
+            if g_pool is not None and i == t - 1:
+                # the last iterate feeds only the pool: (g W2) once per graph, spread and gated per node
+                q = torch.empty(g_pool.shape[0], H, **f32)
+                g_last = g_pool[:, (t - 1) * H:]
+                hip.gemm(g_pool.shape[0], H, H, g_last, _ld(g_last), 1, w2, H, 1, q, H)
+                hip.graph_rows_gated(q, node_graph, bits[i], gh[i])
+            else:
+                g_i = last if i == t - 1 else gx[i]
+                if bits is not None:                                            # through the last Linear + ReLU
+                    hip.gemm_bits(V, H, H, g_i, _ld(g_i), 1, w2, H, 1, gh[i], H, gate_bits=bits[i])
+                else:
+                    hip.gemm(V, H, H, g_i, _ld(g_i), 1, w2, H, 1, gh[i], H, cmask=h[i])
             hip.gemm(V, H, H, gh[i], H, 1, w1, H, 1, ga, H)                     # through the first Linear
             first = i == t - 1
             if i > 0:
-                hip.gine_aggregate_bwd(all_x[:, (i - 1) * H:i * H], table, ga, csr.t_row_ptr, csr.t_col, csr.t_cls,
-                                       gx[i - 1], g_table, add=None if only_last else g_all[:, (i - 1) * H:i * H],
-                                       accumulate_table=not first)
+                slot = slice((i - 1) * H, i * H)
+                add = None if (only_last or g_pool is not None) else g_all[:, slot]
+                seg_add = g_pool[:, slot] if g_pool is not None else None
+                aggregate_bwd(i, None if all_x is None else all_x[:, slot], gx[i - 1], add, seg_add, first)
             else:
-                hip.gine_aggregate_bwd(x0, table, ga, csr.t_row_ptr, csr.t_col, csr.t_cls, g_x0, g_table,
-                                       accumulate_table=not first)
+                aggregate_bwd(i, x0, g_x0, None, None, first)
         need = ctx.needs_input_grad
         gw2, gb2 = torch.empty_like(w2), torch.empty(H, **f32)
         gw1, gb1 = torch.empty_like(w1), torch.empty(H, **f32)
@@ -282,10 +359,23 @@ class _GineEncoder(Function):
         if t > 1:     # layers 0 .. t-2 as one product over their stacked rows, then the last layer's block on top
             SV = (t - 1) * V
             hip.gemm(H, H, SV, gx.view(-1, H)[:SV], 1, H, h.view(TV, H)[:SV], H, 1, gw2, H, split_k=0, rowsum=gb2)
-        hip.gemm(H, H, V, last, 1, _ld(last), h[t - 1], H, 1, gw2, H, split_k=0, rowsum=gb2, accumulate=t > 1)
+        if g_pool is not None:
+            # sum over nodes of g[graph(v)]^T h[v] = sum over graphs of g[b]^T (sum of the graph's rows of h); with
+            # the graph's row scaled by its node count and the row sums turned into means, the bias
+            # gradient (the count-weighted sum of the graphs' rows) is the product's row sum
+            B = g_pool.shape[0]
+            hsum = torch.empty(B, H, **f32)
+            hip.segment_sum_fwd(h[t - 1], pool.begin, pool.end, hsum)
+            counts = pool.counts()
+            hmean = hsum / counts.clamp(min=1.0)[:, None]
+            gpn = g_pool[:, (t - 1) * H:] * counts[:, None]
+            hip.gemm(H, H, B, gpn, 1, H, hmean, H, 1, gw2, H, split_k=0, rowsum=gb2, accumulate=t > 1)
+        else:
+            hip.gemm(H, H, V, last, 1, _ld(last), h[t - 1], H, 1, gw2, H, split_k=0, rowsum=gb2, accumulate=t > 1)
         hip.gemm(H, H, TV, gh2, 1, H, a2, H, 1, gw1, H, split_k=0, rowsum=gb1)
+        tail = (None,) * 4
         if w0 is None:
-            return g_x0, None, None, g_table, gw1, gb1, gw2, gb2, None, None, None
+            return (g_x0, None, None, g_table, gw1, gb1, gw2, gb2) + tail
         Din = x_in.shape[1]
         gw0, gb0 = torch.empty_like(w0), torch.empty(H, **f32)
         hip.gemm(H, Din, V, g_x0, 1, H, x_in, _ld(x_in), 1, gw0, Din, split_k=0, rowsum=gb0)
@@ -293,12 +383,15 @@ class _GineEncoder(Function):
         if need[0]:
             g_in = torch.empty(V, Din, **f32)
             hip.gemm(V, Din, H, g_x0, H, 1, w0, Din, 1, g_in, Din)
-        return g_in, gw0, gb0, g_table, gw1, gb1, gw2, gb2, None, None, None
+        return (g_in, gw0, gb0, g_table, gw1, gb1, gw2, gb2) + tail
 
 
-def gine_encoder(x_in, w0, b0, table, w1, b1, w2, b2, csr, t, only_last=False):
-    """[V, t*H] concatenation of the t GINE iterates of node_trans(x_in); only_last: the last one, [V,H]."""
-    return _GineEncoder.apply(x_in, w0, b0, table, w1, b1, w2, b2, csr, t, only_last)
+def gine_encoder(x_in, w0, b0, table, w1, b1, w2, b2, csr, t, only_last=False, pool=None):
+    """[V, t*H] concatenation of the t GINE iterates of node_trans(x_in); only_last: the last one, [V,H];
+    pool (Segments that cover all rows): their sums over each graph's nodes, [B, t*H]."""
+    if pool is not None and (only_last or not pool.covers_all_rows):
+        raise ValueError('gine_encoder: pooling needs segments that cover all rows, and all iterates')
+    return _GineEncoder.apply(x_in, w0, b0, table, w1, b1, w2, b2, csr, t, only_last, pool)
 
 
 # ------------------------------------------------------------------------ embed_atom

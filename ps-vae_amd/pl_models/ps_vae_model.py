@@ -88,8 +88,7 @@ class PSVAEModel(nn.Module):
             # (small batches are bound by the host's launch rate, where a second stream only adds joins)
             fork = self.two_streams and compact.num_nodes >= self.two_streams_min_nodes
             node_embedding = self.decoder.embed_nodes_async(x, compact.csr_in) if fork else None
-            _, all_x = self.encoder.embed_node(x, compact.csr)
-            graph_embedding = self.encoder.embed_graph(all_x, compact.segments)
+            graph_embedding = self.encoder.embed_graph_of_nodes(x, compact.csr, compact.segments)
             batch_size = compact.num_graphs
             z, res = self.decoder(x=x, x_pieces=None, x_pos=None, edge_index=compact.csr_in, edge_attr=None,
                                   pieces=batch.pieces, conds=graph_embedding, edge_select=compact.pairs,

@@ -450,6 +450,118 @@ def test_gine_aggregate_fwd_bwd(V, H, C):
     close(td.grad, table.grad, what='d aggregate / dtable')
 
 
+@pytest.mark.parametrize('V,H,C', [(1, 4, 1), (50, 36, 4), (5000, 300, 4), (333, 128, 7)])
+def test_gine_aggregate_with_message_bits(V, H, C):
+    """psvae_gine_aggregate_fwd_bits / _bwd_bits: the same results as the plain pair, bit for bit (the
+    bits ARE the comparisons the plain backward recomputes from x and the table), and the per-graph
+    add rows equal the same rows spread to the nodes."""
+    from ps_vae_amd import hip, ops
+    d = dev()
+    ei, attr, x, table = random_graph(V, H, C, seed=V)
+    g = torch.Generator().manual_seed(V + 1)
+    gy, add = torch.randn(V, H, generator=g).to(d), torch.randn(V, H, generator=g).to(d)
+    xd, td = x.to(d), table.to(d)
+    csr = ops.Csr.from_edge_index(ei.to(d), attr.to(d), V)
+    want_out, got_out = torch.empty(V, H, device=d), torch.empty(V, H, device=d)
+    words, wtype = hip.gine_mask_words(V, H, C)
+    mask = torch.zeros(words, dtype=wtype, device=d)
+    hip.gine_aggregate_fwd(xd, td, csr.row_ptr, csr.col, csr.cls, want_out)
+    hip.gine_aggregate_fwd_bits(xd, td, csr.row_ptr, csr.col, csr.cls, got_out, mask)
+    assert torch.equal(got_out, want_out)
+    # the bits themselves: element e of column block c of node j under class k
+    pre = (x[:, None, :] + table[None, :, :]) > 0                                     # [V, C, H]
+    e = torch.arange(H)
+    weights = (1 << (4 * torch.arange(C)[:, None] + (e % 4)[None, :])).to(torch.int64)   # [C, H]
+    want_bits = (pre.to(torch.int64) * weights[None]).sum(1).view(V, H // 4, 4).sum(-1)  # [V, H/4]
+    got_bits = mask.cpu().to(torch.int64) & ((1 << (4 * C)) - 1)      # (bits of classes beyond C are not defined)
+    assert torch.equal(got_bits.view(V, H // 4), want_bits)
+    want_gx, got_gx = torch.empty(V, H, device=d), torch.empty(V, H, device=d)
+    want_gt, got_gt = torch.full((C, H), 0.5, device=d), torch.full((C, H), 0.5, device=d)
+    hip.gine_aggregate_bwd(xd, td, gy, csr.t_row_ptr, csr.t_col, csr.t_cls, want_gx, want_gt, add=add, accumulate_table=True)
+    hip.gine_aggregate_bwd_bits(mask, C, gy, csr.t_row_ptr, csr.t_col, csr.t_cls, got_gx, got_gt, add=add,
+                                accumulate_table=True)
+    assert torch.equal(got_gx, want_gx) and torch.equal(got_gt, want_gt)
+    # per-graph rows: graphs of 1..7 nodes, a column block of a wider matrix as the row source
+    sizes = []
+    while sum(sizes) < V:
+        sizes.append(min(int(torch.randint(1, 8, (1,), generator=g)), V - sum(sizes)))
+    node_graph = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes)).to(torch.int32).to(d)
+    wide = torch.randn(len(sizes), 2 * H + 4, generator=g).to(d)
+    seg = wide[:, 4:4 + H]
+    hip.gine_aggregate_bwd(xd, td, gy, csr.t_row_ptr, csr.t_col, csr.t_cls, want_gx, want_gt,
+                           add=seg[node_graph.long()].contiguous())
+    hip.gine_aggregate_bwd_bits(mask, C, gy, csr.t_row_ptr, csr.t_col, csr.t_cls, got_gx, got_gt, seg_add=seg,
+                                node_graph=node_graph)
+    assert torch.equal(got_gx, want_gx) and torch.equal(got_gt, want_gt)
+
+
+@pytest.mark.parametrize('V,N,B', [(1, 4, 1), (95, 300, 7), (4100, 328, 300), (64, 32, 64)])
+def test_graph_rows_gated(V, N, B):
+    """out[v] = q[graph(v)] where the product's sign bit is set: the bits come from a real
+    psvae_gemm_f32_bits call, the expectation from its full-width result."""
+    from ps_vae_amd import hip
+    d = dev()
+    g = torch.Generator().manual_seed(V + N)
+    node_graph = torch.sort(torch.randint(0, B, (V,), generator=g)).values.to(torch.int32).to(d)
+    q = torch.randn(B, N + 4, generator=g).to(d)[:, :N]
+    if V >= 32:
+        a, w = torch.randn(V, 16, generator=g).to(d), torch.randn(N, 16, generator=g).to(d)
+        act = torch.empty(V, N, device=d)
+        bits = torch.zeros(hip.gemm_bits_words(V, N), dtype=torch.int64, device=d)
+        hip.gemm_bits(V, N, 16, a, 16, 1, w, 1, 16, act, N, relu=True, relu_bits=bits)
+        keep = act > 0
+    else:   # below the bit product's row minimum: bits set by hand in its layout
+        keep = torch.rand(V, N, generator=g).to(d) > 0.5
+        words = torch.zeros(hip.gemm_bits_words(V, N), dtype=torch.int64)
+        kc = keep.cpu()
+        for r in range(V):
+            for c in range(N):
+                if kc[r, c]:
+                    idx = ((r // 32) * ((N + 31) // 32) + c // 32) * 16 + 4 * ((r % 32) // 8) + (c % 4)
+                    lane = 8 * (r % 8) + (c % 32) // 4
+                    words[idx] |= (1 << lane) if lane < 63 else -(1 << 63)
+        bits = words.to(d)
+    out = torch.full((V, N + 4), 9.0, device=d)
+    hip.graph_rows_gated(q, node_graph, bits, out[:, :N])
+    want = torch.where(keep, q[node_graph.long()], torch.zeros((), device=d))
+    assert torch.equal(out[:, :N], want) and bool((out[:, N:] == 9.0).all())
+
+
+@pytest.mark.parametrize('B,H,t', [(300, 300, 4), (5, 36, 2), (40, 300, 1)])
+def test_gine_encoder_pooled_backward(B, H, t):
+    """ops.gine_encoder(..., pool=segments) - the sum over each graph's nodes taken inside the node,
+    its backward working from one gradient row per graph - against the same encoder followed by
+    ops.segment_sum: equal outputs, gradients of every input within 1e-5."""
+    from ps_vae_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(B + H)
+    sizes = torch.randint(1, 30, (B,), generator=g)
+    V = int(sizes.sum())
+    off = torch.zeros(B + 1, dtype=torch.int32)
+    off[1:] = torch.cumsum(sizes, 0)
+    ei, attr, x, table = random_graph(V, H, 4, seed=B)
+    csr = ops.Csr.from_edge_index(ei.to(d), attr.to(d), V)
+    segs = ops.Segments.from_offsets(off.to(d))
+    w1, w2 = torch.randn(H, H, generator=g) / H ** 0.5, torch.randn(H, H, generator=g) / H ** 0.5
+    b1, b2 = torch.randn(H, generator=g) * 0.1, torch.randn(H, generator=g) * 0.1
+    gout = torch.randn(B, t * H, generator=g).to(d)
+
+    def run(pool):
+        leaves = [v.clone().to(d).requires_grad_(True) for v in (x, table, w1, b1, w2, b2)]
+        xs, tb, a1, c1, a2, c2 = leaves
+        if pool:
+            out = ops.gine_encoder(xs, None, None, tb, a1, c1, a2, c2, csr, t, False, segs)
+        else:
+            out = ops.segment_sum(ops.gine_encoder(xs, None, None, tb, a1, c1, a2, c2, csr, t), segs)
+        out.backward(gout)
+        return out.detach(), [v.grad for v in leaves]
+    out_a, grads_a = run(False)
+    out_b, grads_b = run(True)
+    assert torch.equal(out_a, out_b)
+    for ga, gb, name in zip(grads_a, grads_b, ('x', 'table', 'w1', 'b1', 'w2', 'b2')):
+        close(gb, ga, what=f'pooled encoder: d/d{name}')
+
+
 def test_gine_aggregate_strided_rows():
     from ps_vae_amd import hip, ops
     d = dev()

@@ -1,15 +1,17 @@
 #!/bin/bash
-# A/B build of the library with extra -D flags (every object is rebuilt, in a scratch copy of the
-# sources):  tools/build_variant.sh NAME "-DPSVAE_PANEL_OCC=2 ..."  ->  exp_libs/libpsvae_NAME.so
+# A/B build of the kernel library: tools/build_variant.sh <name> "<extra hipcc flags>" ["<panel list>"]
+# compiles a copy of ps-vae_amd/csrc in /tmp and leaves exp_libs/libpsvae_<name>.so (run it with
+# PSVAE_HIP_LIB=exp_libs/libpsvae_<name>.so).
 set -e
-ROOT="$(cd "$(dirname "$0")/.." && pwd)"
-NAME=$1; DEFS=$2
-TMP=/tmp/psvae_variant_$NAME
-rm -rf $TMP && mkdir -p $TMP/ps-vae_amd $TMP/include
-cp $ROOT/include/*.h $TMP/include/
-mkdir -p $TMP/ps-vae_amd/csrc
-cp $ROOT/ps-vae_amd/csrc/*.hip $ROOT/ps-vae_amd/csrc/*.h $ROOT/ps-vae_amd/csrc/Makefile $TMP/ps-vae_amd/csrc/
-make -C $TMP/ps-vae_amd/csrc -j8 EXTRA="$DEFS" libpsvae_hip.so >/dev/null
-mkdir -p $ROOT/exp_libs
-cp $TMP/ps-vae_amd/csrc/libpsvae_hip.so $ROOT/exp_libs/libpsvae_$NAME.so
-echo built $ROOT/exp_libs/libpsvae_$NAME.so
+NAME=$1; EXTRA=$2; PANELS=$3
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+W=/tmp/psvae_build_$NAME
+rm -rf $W && mkdir -p $W/ps-vae_amd && cp -r $ROOT/include $W/ && mkdir -p $W/ps-vae_amd/csrc
+cp $ROOT/ps-vae_amd/csrc/*.hip $ROOT/ps-vae_amd/csrc/*.h $ROOT/ps-vae_amd/csrc/*.cpp $ROOT/ps-vae_amd/csrc/Makefile $W/ps-vae_amd/csrc/
+if [ -n "$PANELS" ]; then
+  make -C $W/ps-vae_amd/csrc -j8 libpsvae_hip.so EXTRA="$EXTRA" PANELS="$PANELS" > $W/build.log 2>&1
+else
+  make -C $W/ps-vae_amd/csrc -j8 libpsvae_hip.so EXTRA="$EXTRA" > $W/build.log 2>&1
+fi
+mkdir -p $ROOT/exp_libs && cp $W/ps-vae_amd/csrc/libpsvae_hip.so $ROOT/exp_libs/libpsvae_$NAME.so
+echo built exp_libs/libpsvae_$NAME.so
