@@ -146,14 +146,28 @@ def pmc_traffic(batch):
 
 
 def small_batch_record(model_factory, tok, shape, B, steps, warmup, dev):
-    """A short training run at batch B (BASELINE.json configs[0] / configs[1] shapes) on the
-    same code path: molecules/s, ms per step and C-ABI calls per step."""
+    """A short training run at batch B (BASELINE.json configs[0] / configs[1] shapes): the step recorded
+    once in a HIP graph over fixed-size padded buffers and replayed (graph_step.GraphedTrainStep;
+    collation of every batch stays outside the recording), beside the same step launched kernel by
+    kernel.  The roofline is the whole step's: matrix-product flops of one step (counted on an
+    ordinary step of the same model) over the step time."""
     from ps_vae_amd import hip
-    model, opt = model_factory()
+    from ps_vae_amd.graph_step import GraphedTrainStep
     dataset = make_dataset(64 * B, 7, tok, dev, shape=shape)
     rng = np.random.default_rng(3)
 
-    def step():
+    def timed(step_fn, n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step_fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+
+    # the ordinary step
+    model, opt = model_factory()
+
+    def eager_step():
         batch = dataset.collate_ids(rng.choice(len(dataset), size=B, replace=False))
         opt.zero_grad()
         model.training_step(batch, 0).backward()
@@ -161,16 +175,38 @@ def small_batch_record(model_factory, tok, shape, B, steps, warmup, dev):
         model.global_step += 1
 
     for _ in range(warmup):
-        step()
-    torch.cuda.synchronize()
+        eager_step()
     calls0 = hip.CALLS
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
+    dt_eager = timed(eager_step, steps)
+    calls = (hip.CALLS - calls0) // steps
+    hip.PROFILE = prof = {}
+    eager_step()
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    return {'value': round(B * steps / dt, 1), 'unit': 'molecules/s', 'ms_per_step': round(dt / steps * 1e3, 3),
-            'batch': B, 'shape': shape, 'steps': steps, 'abi_calls_per_step': (hip.CALLS - calls0) // steps}
+    hip.PROFILE = None
+    flops = sum(it[2] for it in prof.get('gemm_f32_kernel', []))
+    gemm_ms = sum(it[0].elapsed_time(it[1]) for it in prof.get('gemm_f32_kernel', []))
+    # the recorded step
+    model, opt = model_factory()
+    graphed = GraphedTrainStep(model, opt, dataset, B)
+
+    def graph_step():
+        graphed.step(rng.choice(len(dataset), size=B, replace=False))
+
+    for _ in range(warmup):
+        graph_step()
+    dt = timed(graph_step, steps)
+    tflops = flops / dt / 1e12
+    return {'value': round(B / dt, 1), 'unit': 'molecules/s', 'ms_per_step': round(dt * 1e3, 3), 'batch': B, 'shape': shape,
+            'steps': steps, 'mode': 'one HIP-graph launch per step (fixed-size padded batch), collation outside the recording',
+            'graph_replays': graphed.replays, 'ordinary_fallbacks': graphed.fallbacks, 'padded_shapes': repr(graphed.shapes),
+            'kernel_by_kernel': {'value': round(B / dt_eager, 1), 'ms_per_step': round(dt_eager * 1e3, 3),
+                                 'abi_calls_per_step': calls},
+            'roofline': {'bound': 'mfma', 'scope': 'whole step (all kernels and gaps), matrix-product flops only',
+                         'achieved': round(tflops, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': round(tflops / MFMA_F32_PEAK_TFLOPS, 4), 'gemm_gflop_per_step': round(flops / 1e9, 2),
+                         'gemm_kernels_alone_ms': round(gemm_ms, 3),
+                         'gemm_kernels_alone_frac': round(flops / (gemm_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4) if gemm_ms else None,
+                         'traffic': None}}
 
 
 def generation_record(model, dev, n_mol=10000, reps=3):

@@ -413,12 +413,15 @@ int psvae_affine_merge_bwd(int C, int J, int K, const float *w_last, const float
  * dlogits[p] = (softmax(logits[p]) - onehot(golden[p])) / P;
  * n_correct = #{p : argmax(logits[p]) == golden[p]} (first maximum, as torch.argmax).
  * P == 0 gives loss = NaN like torch's mean over an empty batch.
+ * live_count (optional, device int32): only rows 0 .. *live_count - 1 are pairs, the rest of the P
+ * rows is padding of a fixed-size buffer (zero logits, zero dlogits, no part in the mean or in
+ * n_correct) - the count is read on the device when the kernel runs.
  * psvae_link_ce_bwd_input: g_hid[p][f] = g_loss * sum_c dlogits[p][c] * W[c][f].
  * ---------------------------------------------------------------------------------- */
 size_t psvae_link_ce_workspace_bytes(int P);
 int psvae_link_ce_fwd(int P, int F, int C, const float *hid, int ldhid, const float *W,
-                      const float *b, const int32_t *golden, float *logits, float *dlogits,
-                      float *loss, int32_t *n_correct,
+                      const float *b, const int32_t *golden, const int32_t *live_count,
+                      float *logits, float *dlogits, float *loss, int32_t *n_correct,
                       void *workspace, size_t workspace_bytes, void *stream);
 int psvae_link_ce_bwd_input(int P, int F, int C, const float *dlogits, const float *W,
                             const float *g_loss, float *g_hid, int ldg, void *stream);
@@ -498,6 +501,15 @@ int psvae_clip_adam_step(long long n, float *p, float *g, float *m, float *v, fl
                          float max_norm, double lr, double beta1, double beta2, double eps,
                          double weight_decay, int step, int write_grad, float *norm_out,
                          void *workspace, size_t workspace_bytes, void *stream);
+
+/* The same step with the two step-dependent scalars read from DEVICE memory when the kernel runs:
+ * step_scalars[0] = lr / (1 - beta1^t), step_scalars[1] = sqrt(1 - beta2^t) (the caller evaluates
+ * them in double and stores them as float).  For a step recorded once in a HIP graph and replayed:
+ * nothing that changes from step to step is a kernel argument. */
+int psvae_clip_adam_step_dev(long long n, float *p, float *g, float *m, float *v, float grad_scale,
+                             float max_norm, double beta1, double beta2, double eps, double weight_decay,
+                             const float *step_scalars, int write_grad, float *norm_out,
+                             void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -536,7 +536,8 @@ __global__ __launch_bounds__(256) void link_ce_fwd_kernel(int P, int F, int C, c
                                                           const float *__restrict__ bias,
                                                           const int32_t *__restrict__ golden,
                                                           float *__restrict__ logits, float *__restrict__ dlogits,
-                                                          float *__restrict__ part_loss, int *__restrict__ part_ok) {
+                                                          float *__restrict__ part_loss, int *__restrict__ part_ok,
+                                                          const int32_t *__restrict__ live) {
     extern __shared__ __align__(16) float sW[];
     __shared__ float sh_loss[4];
     __shared__ int sh_ok[4];
@@ -547,7 +548,13 @@ __global__ __launch_bounds__(256) void link_ce_fwd_kernel(int P, int F, int C, c
     }
     float loss_acc = 0.f;
     int ok_acc = 0;
+    // rows from *live on (when given) are padding: zero logits and gradient, no part in the mean
+    const int P_live = live ? min(P, max(*live, 0)) : P;
     for (int p = blockIdx.x * 4 + wave; p < P; p += gridDim.x * 4) {
+        if (p >= P_live) {   // wave-uniform
+            if (lane < C) logits[(long long)p * C + lane] = 0.f, dlogits[(long long)p * C + lane] = 0.f;
+            continue;
+        }
         float dot[MAXC];
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) dot[c] = 0.f;
@@ -598,7 +605,7 @@ __global__ __launch_bounds__(256) void link_ce_fwd_kernel(int P, int F, int C, c
                 if (c < C) {
                     if (c == gold) lg = dot[c];
                     logits[(long long)p * C + c] = dot[c];
-                    dlogits[(long long)p * C + c] = (expf(dot[c] - lse) - (c == gold ? 1.f : 0.f)) / (float)P;
+                    dlogits[(long long)p * C + c] = (expf(dot[c] - lse) - (c == gold ? 1.f : 0.f)) / (float)P_live;
                 }
             loss_acc += lse - lg;
             ok_acc += (arg == gold);
@@ -614,7 +621,7 @@ __global__ __launch_bounds__(256) void link_ce_fwd_kernel(int P, int F, int C, c
 
 __global__ void link_ce_finish_kernel(int P, int n_part, const float *__restrict__ part_loss,
                                       const int *__restrict__ part_ok, float *__restrict__ loss,
-                                      int32_t *__restrict__ n_correct) {
+                                      int32_t *__restrict__ n_correct, const int32_t *__restrict__ live) {
     __shared__ float sh_s[256];
     __shared__ int sh_ok[256];
     float s = 0.f;
@@ -627,7 +634,8 @@ __global__ void link_ce_finish_kernel(int P, int n_part, const float *__restrict
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        *loss = sh_s[0] / (float)P;   // 0/0 = NaN for P == 0, as torch's mean over no rows
+        const int P_live = live ? min(P, max(*live, 0)) : P;
+        *loss = sh_s[0] / (float)P_live;   // 0/0 = NaN for no rows, as torch's mean over no rows
         if (n_correct) *n_correct = sh_ok[0];
     }
 }
@@ -1013,8 +1021,8 @@ extern "C" size_t psvae_link_ce_workspace_bytes(int P) {
 }
 
 extern "C" int psvae_link_ce_fwd(int P, int F, int C, const float *hid, int ldhid, const float *W, const float *b,
-                                 const int32_t *golden, float *logits, float *dlogits, float *loss, int32_t *n_correct,
-                                 void *workspace, size_t workspace_bytes, void *stream) {
+                                 const int32_t *golden, const int32_t *live_count, float *logits, float *dlogits,
+                                 float *loss, int32_t *n_correct, void *workspace, size_t workspace_bytes, void *stream) {
     PSVAE_REQUIRE(P >= 0 && F > 0 && C > 0, PSVAE_EINVAL, "psvae_link_ce_fwd: bad sizes");
     PSVAE_REQUIRE(C <= 8, PSVAE_ETOOLARGE, "psvae_link_ce_fwd: at most 8 classes (C=%d)", C);
     PSVAE_REQUIRE(loss != nullptr && W != nullptr, PSVAE_EINVAL, "psvae_link_ce_fwd: null pointer");
@@ -1032,7 +1040,7 @@ extern "C" int psvae_link_ce_fwd(int P, int F, int C, const float *hid, int ldhi
     const size_t shm = ldsw ? w_bytes : 0;
 #define PSVAE_LINK_CE(MAXC, VEC, LDSW)                                                                            \
     hipLaunchKernelGGL((link_ce_fwd_kernel<MAXC, VEC, LDSW>), dim3(blocks), dim3(256), shm, s, P, F, C, hid, ldhid, \
-                       W, b, golden, logits, dlogits, part_loss, part_ok)
+                       W, b, golden, logits, dlogits, part_loss, part_ok, live_count)
     if (C <= 4) {
         if (vec && ldsw) PSVAE_LINK_CE(4, true, true);
         else if (ldsw) PSVAE_LINK_CE(4, false, true);
@@ -1044,7 +1052,8 @@ extern "C" int psvae_link_ce_fwd(int P, int F, int C, const float *hid, int ldhi
     }
 #undef PSVAE_LINK_CE
     PSVAE_CHECK_LAUNCH("psvae_link_ce_fwd");
-    hipLaunchKernelGGL(link_ce_finish_kernel, dim3(1), dim3(256), 0, s, P, blocks, part_loss, part_ok, loss, n_correct);
+    hipLaunchKernelGGL(link_ce_finish_kernel, dim3(1), dim3(256), 0, s, P, blocks, part_loss, part_ok, loss, n_correct,
+                       live_count);
     PSVAE_CHECK_LAUNCH("psvae_link_ce_fwd (finish)");
     return PSVAE_OK;
 }

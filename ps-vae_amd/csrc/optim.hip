@@ -75,16 +75,18 @@ struct AdamArgs {
     float beta2, omb1, omb2, eps, step_size, bc2_sqrt, weight_decay;   // omb = 1 - beta, rounded once from double
     int write_grad;               // store the scaled + clipped gradient back (what clip_grad_norm_ leaves in .grad)
     float *norm_out;              // optional: the global norm before clipping
+    const float *dev_scalars;     // optional, device [2]: step_size and bc2_sqrt read at run time instead of the two above
 };
 
-__device__ __forceinline__ void adam_one(const AdamArgs &a, float coef, float &p, float &g, float &m, float &v) {
+__device__ __forceinline__ void adam_one(const AdamArgs &a, float coef, float step_size, float bc2_sqrt, float &p, float &g,
+                                         float &m, float &v) {
     g = g * coef;
     float gg = g;
     if (a.weight_decay != 0.f) gg += a.weight_decay * p;
     m = m + (gg - m) * a.omb1;
     v = v * a.beta2 + a.omb2 * gg * gg;
-    const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
-    p = p - a.step_size * (m / denom);
+    const float denom = sqrtf(v) / bc2_sqrt + a.eps;
+    p = p - step_size * (m / denom);
 }
 
 __global__ __launch_bounds__(OPT_THREADS) void clip_adam_kernel(AdamArgs a) {
@@ -100,16 +102,17 @@ __global__ __launch_bounds__(OPT_THREADS) void clip_adam_kernel(AdamArgs a) {
             coef *= c < 1.f ? c : 1.f;
         }
     }
+    const float ss = a.dev_scalars ? a.dev_scalars[0] : a.step_size, bq = a.dev_scalars ? a.dev_scalars[1] : a.bc2_sqrt;
     const long long begin = (long long)blockIdx.x * a.chunk;
     const long long end = begin + a.chunk < a.n ? begin + a.chunk : a.n;
     const long long end4 = begin + ((end - begin) & ~3ll);
     for (long long i = begin + 4ll * threadIdx.x; i < end4; i += 4ll * OPT_THREADS) {
         float4 p = *reinterpret_cast<float4 *>(a.p + i), g = *reinterpret_cast<const float4 *>(a.g + i);
         float4 m = *reinterpret_cast<float4 *>(a.m + i), v = *reinterpret_cast<float4 *>(a.v + i);
-        adam_one(a, coef, p.x, g.x, m.x, v.x);
-        adam_one(a, coef, p.y, g.y, m.y, v.y);
-        adam_one(a, coef, p.z, g.z, m.z, v.z);
-        adam_one(a, coef, p.w, g.w, m.w, v.w);
+        adam_one(a, coef, ss, bq, p.x, g.x, m.x, v.x);
+        adam_one(a, coef, ss, bq, p.y, g.y, m.y, v.y);
+        adam_one(a, coef, ss, bq, p.z, g.z, m.z, v.z);
+        adam_one(a, coef, ss, bq, p.w, g.w, m.w, v.w);
         *reinterpret_cast<float4 *>(a.p + i) = p;
         *reinterpret_cast<float4 *>(a.m + i) = m;
         *reinterpret_cast<float4 *>(a.v + i) = v;
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(OPT_THREADS) void clip_adam_kernel(AdamArgs a) {
     }
     for (long long i = end4 + threadIdx.x; i < end; i += OPT_THREADS) {
         float p = a.p[i], g = a.g[i], m = a.m[i], v = a.v[i];
-        adam_one(a, coef, p, g, m, v);
+        adam_one(a, coef, ss, bq, p, g, m, v);
         a.p[i] = p, a.m[i] = m, a.v[i] = v;
         if (a.write_grad) a.g[i] = g;
     }
@@ -135,17 +138,16 @@ extern "C" size_t psvae_clip_adam_workspace_bytes(long long n) {
     return (size_t)opt_blocks(n) * sizeof(float);
 }
 
-extern "C" int psvae_clip_adam_step(long long n, float *p, float *g, float *m, float *v, float grad_scale,
-                                    float max_norm, double lr, double beta1, double beta2, double eps,
-                                    double weight_decay, int step, int write_grad, float *norm_out, void *workspace,
-                                    size_t workspace_bytes, void *stream) {
-    const char *fn = "psvae_clip_adam_step";
+static int clip_adam_impl(const char *fn, long long n, float *p, float *g, float *m, float *v, float grad_scale,
+                          float max_norm, double lr, double beta1, double beta2, double eps, double weight_decay, int step,
+                          const float *dev_scalars, int write_grad, float *norm_out, void *workspace,
+                          size_t workspace_bytes, void *stream) {
     PSVAE_REQUIRE(n >= 0, PSVAE_EINVAL, "%s: negative length", fn);
     if (n == 0) return PSVAE_OK;
     PSVAE_REQUIRE(p && g && m && v, PSVAE_EINVAL, "%s: null buffer", fn);
     PSVAE_REQUIRE(psvae_aligned16(p) && psvae_aligned16(g) && psvae_aligned16(m) && psvae_aligned16(v), PSVAE_EINVAL,
                   "%s: buffers must be 16-byte aligned", fn);
-    PSVAE_REQUIRE(step >= 1, PSVAE_EINVAL, "%s: step counts from 1 (got %d)", fn, step);
+    PSVAE_REQUIRE(dev_scalars != nullptr || step >= 1, PSVAE_EINVAL, "%s: step counts from 1 (got %d)", fn, step);
     PSVAE_REQUIRE(beta1 >= 0. && beta1 < 1. && beta2 >= 0. && beta2 < 1. && eps >= 0., PSVAE_EINVAL,
                   "%s: bad hyper-parameters", fn);
     PSVAE_REQUIRE(workspace && workspace_bytes >= psvae_clip_adam_workspace_bytes(n), PSVAE_EWORKSPACE,
@@ -158,9 +160,13 @@ extern "C" int psvae_clip_adam_step(long long n, float *p, float *g, float *m, f
     a.grad_scale = grad_scale, a.max_norm = max_norm, a.beta2 = (float)beta2, a.eps = (float)eps;
     a.omb1 = (float)(1.0 - beta1), a.omb2 = (float)(1.0 - beta2);
     a.weight_decay = (float)weight_decay, a.write_grad = write_grad, a.norm_out = norm_out;
-    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
-    a.step_size = (float)(lr / bc1);
-    a.bc2_sqrt = (float)sqrt(bc2);
+    a.dev_scalars = dev_scalars;
+    a.step_size = 0.f, a.bc2_sqrt = 1.f;
+    if (dev_scalars == nullptr) {
+        const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+        a.step_size = (float)(lr / bc1);
+        a.bc2_sqrt = (float)sqrt(bc2);
+    }
     if (max_norm > 0.f || norm_out != nullptr) {
         hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(blocks), dim3(OPT_THREADS), 0, s, n, a.chunk, (const float *)g,
                            grad_scale, (float *)workspace);
@@ -169,4 +175,22 @@ extern "C" int psvae_clip_adam_step(long long n, float *p, float *g, float *m, f
     hipLaunchKernelGGL(clip_adam_kernel, dim3(blocks), dim3(OPT_THREADS), 0, s, a);
     PSVAE_CHECK_LAUNCH(fn);
     return PSVAE_OK;
+}
+
+extern "C" int psvae_clip_adam_step(long long n, float *p, float *g, float *m, float *v, float grad_scale,
+                                    float max_norm, double lr, double beta1, double beta2, double eps,
+                                    double weight_decay, int step, int write_grad, float *norm_out, void *workspace,
+                                    size_t workspace_bytes, void *stream) {
+    return clip_adam_impl("psvae_clip_adam_step", n, p, g, m, v, grad_scale, max_norm, lr, beta1, beta2, eps, weight_decay, step,
+                          nullptr, write_grad, norm_out, workspace, workspace_bytes, stream);
+}
+
+extern "C" int psvae_clip_adam_step_dev(long long n, float *p, float *g, float *m, float *v, float grad_scale,
+                                        float max_norm, double beta1, double beta2, double eps, double weight_decay,
+                                        const float *step_scalars, int write_grad, float *norm_out, void *workspace,
+                                        size_t workspace_bytes, void *stream) {
+    const char *fn = "psvae_clip_adam_step_dev";
+    PSVAE_REQUIRE(step_scalars != nullptr, PSVAE_EINVAL, "%s: step_scalars is null", fn);
+    return clip_adam_impl(fn, n, p, g, m, v, grad_scale, max_norm, 0.0, beta1, beta2, eps, weight_decay, 0, step_scalars,
+                          write_grad, norm_out, workspace, workspace_bytes, stream);
 }

@@ -244,9 +244,9 @@ void pair_combine_bwd(const Tensor &g_out, const OptTensor &out, bool relu, cons
           fn);
 }
 
-void link_ce_fwd(const Tensor &hid, const Tensor &W, const OptTensor &b, const Tensor &golden, Tensor logits, Tensor dlogits,
-                 Tensor loss, Tensor n_correct) {
-    PSVAE_ON_DEVICE("psvae::link_ce_fwd", p(hid), p(W), p(b), p(golden), p(logits), p(dlogits), p(loss), p(n_correct));
+void link_ce_fwd(const Tensor &hid, const Tensor &W, const OptTensor &b, const Tensor &golden, const OptTensor &live,
+                 Tensor logits, Tensor dlogits, Tensor loss, Tensor n_correct) {
+    PSVAE_ON_DEVICE("psvae::link_ce_fwd", p(hid), p(W), p(b), p(golden), p(live), p(logits), p(dlogits), p(loss), p(n_correct));
     const char *fn = "psvae_link_ce_fwd";
     const int P = (int)hid.size(0), F = (int)hid.size(1);
     void *s = cur_stream(W);
@@ -254,7 +254,8 @@ void link_ce_fwd(const Tensor &hid, const Tensor &W, const OptTensor &b, const T
     Tensor hold = workspace(nbytes, W, s);
     TORCH_CHECK(n_correct.is_cuda() && n_correct.scalar_type() == at::kInt, fn, ": n_correct must be an int32 GPU tensor");
     check(psvae_link_ce_fwd(P, F, (int)W.size(0), P ? f32(hid, fn) : nullptr, P ? (int)row_stride(hid, fn) : F, f32(W, fn),
-                            f32(b, fn), P ? i32(golden, fn) : nullptr, f32_mut(logits, fn), f32_mut(dlogits, fn),
+                            f32(b, fn), P ? i32(golden, fn) : nullptr,
+                            live.has_value() && live->defined() ? i32(*live, fn) : nullptr, f32_mut(logits, fn), f32_mut(dlogits, fn),
                             f32_mut(loss, fn), n_correct.data_ptr<int32_t>(), hold.data_ptr(), nbytes, s),
           fn);
 }
@@ -474,8 +475,8 @@ TORCH_LIBRARY(psvae, m) {
           &pair_combine_fwd);
     m.def("pair_combine_bwd(Tensor g_out, Tensor? out, bool relu, Tensor src, Tensor dst, Tensor pair_ptr, Tensor node_begin, "
           "Tensor node_end, Tensor(a!) g_ab, Tensor(b!) g_c) -> ()", &pair_combine_bwd);
-    m.def("link_ce_fwd(Tensor hid, Tensor W, Tensor? b, Tensor golden, Tensor(a!) logits, Tensor(b!) dlogits, Tensor(c!) loss, "
-          "Tensor(d!) n_correct) -> ()", &link_ce_fwd);
+    m.def("link_ce_fwd(Tensor hid, Tensor W, Tensor? b, Tensor golden, Tensor? live, Tensor(a!) logits, Tensor(b!) dlogits, "
+          "Tensor(c!) loss, Tensor(d!) n_correct) -> ()", &link_ce_fwd);
     m.def("link_ce_bwd_input(Tensor dlogits, Tensor W, Tensor g_loss, Tensor(a!) g_hid) -> ()", &link_ce_bwd_input);
     m.def("segment_sum_fwd(Tensor x, Tensor seg_begin, Tensor seg_end, Tensor(a!) out) -> ()", &segment_sum_fwd);
     m.def("segment_sum_bwd(Tensor g_out, Tensor seg_begin, Tensor seg_end, Tensor(a!) g_x) -> ()", &segment_sum_bwd);

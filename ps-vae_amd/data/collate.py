@@ -196,3 +196,140 @@ def collate_packed(dpacked, ids, uniforms=None, atom_pad=10, piece_pad=300, num_
     if compact_layout:
         out.compact = CompactBatch(cmp_, node_off, pair_off, B, pending)
     return out
+
+
+# ---------------------------------------------------------------------------- fixed-size batches
+class PinnedRing:
+    """A few pinned host buffers used in turn for asynchronous host -> device copies: the host may run
+    several steps ahead of the GPU, so a buffer is rewritten only after the copy that last read it
+    has completed (its event is waited for when the ring comes round)."""
+
+    def __init__(self, shape, dtype, slots=8):
+        self.bufs = [torch.zeros(*shape, dtype=dtype).pin_memory() for _ in range(slots)]
+        self.events = [None] * slots
+        self.i = -1
+
+    def next(self):
+        self.i = (self.i + 1) % len(self.bufs)
+        if self.events[self.i] is not None:
+            self.events[self.i].synchronize()
+        return self.bufs[self.i]
+
+    def sent(self):
+        """Call right after enqueueing the copy out of the buffer next() returned."""
+        event = torch.cuda.Event()
+        event.record()
+        self.events[self.i] = event
+
+
+class StaticShapes:
+    """Sizes of a padded batch that do not change from batch to batch (what a step recorded once in
+    a HIP graph needs): B molecules, V atom rows, E / Ein directed (in-piece) bonds, P candidate
+    pairs, R uniforms, S pieces per molecule, N atoms of the largest molecule.  Rows beyond a
+    batch's own counts are padding that takes no part in any result (see collate_static)."""
+
+    def __init__(self, B, V, E, Ein, P, R, S, N):
+        self.B, self.V, self.E, self.Ein, self.P, self.R, self.S, self.N = (int(v) for v in (B, V, E, Ein, P, R, S, N))
+
+    def __repr__(self):
+        return 'StaticShapes(' + ', '.join(f'{k}={getattr(self, k)}' for k in 'BVEPRSN') + f', Ein={self.Ein})'
+
+    @classmethod
+    def for_dataset(cls, host, B, sigmas=4.0, keep_prob=KEEP_PROB):
+        """Bounds that a batch of B molecules drawn from `host` (PackedMolecules) exceeds with the
+        probability of a `sigmas`-sigma event per quantity (mean x B + sigmas x std x sqrt(B), rounded
+        up to a multiple of 32, never beyond the B largest molecules' total); a batch that does exceed
+        one is collated and stepped the ordinary way.  S and N are the dataset's maxima."""
+        n_atoms = np.diff(host.atom_off).astype(np.float64)
+
+        def bound(per_mol):
+            per_mol = np.asarray(per_mol, dtype=np.float64)
+            stat = per_mol.mean() * B + sigmas * per_mol.std() * np.sqrt(B)
+            worst = np.sort(per_mol)[::-1][:B].sum()
+            return int(min(np.ceil(stat / 32.0) * 32, max(worst, 1)))
+
+        cross_bonds = (host.n_edge - host.n_inpiece).astype(np.float64)       # bonded cross-piece cells (always kept)
+        pairs = cross_bonds + keep_prob * host.n_rng                           # expected kept pairs per molecule
+        pair_var = keep_prob * (1 - keep_prob) * host.n_rng                    # plus the binomial spread of the draws
+        P = pairs.mean() * B + sigmas * np.sqrt((pairs.var() + pair_var.mean()) * B)
+        return cls(B=B, V=bound(n_atoms), E=bound(host.n_edge), Ein=bound(host.n_inpiece),
+                   P=int(np.ceil(P / 32.0) * 32), R=bound(host.n_rng), S=int(np.diff(host.piece_off).max()),
+                   N=int(n_atoms.max()))
+
+
+class StaticBatch:
+    """The device buffers of one fixed-size batch, allocated once and refilled by collate_static:
+    every kernel of a recorded step reads the same addresses on every replay."""
+
+    def __init__(self, shapes, device, num_bond_type=4):
+        s, dev = shapes, torch.device(device)
+        i32, u8 = torch.int32, torch.uint8
+        self.shapes, self.device = s, dev
+        z = lambda n, dt: torch.zeros(n, dtype=dt, device=dev)          # noqa: E731
+        self.offs = z(5 * (s.B + 1), i32).view(5, s.B + 1)
+        self.offs_host = PinnedRing((5, s.B + 1), i32)
+        self.pair_cnt, self.pair_off = z(s.B, i32), z(s.B + 1, i32)
+        slack = s.N * s.N                                               # a molecule that straddles the pair capacity
+        self.t = {'cx': z(s.V, i32), 'cxp': z(s.V, i32), 'cxpos': z(s.V, i32),
+                  'row_ptr': z(s.V + 1, i32), 'col': z(max(s.E, 1), i32), 'cls': z(max(s.E, 1), u8),
+                  'in_row_ptr': z(s.V + 1, i32), 'in_col': z(max(s.Ein, 1), i32), 'in_cls': z(max(s.Ein, 1), u8),
+                  'pair_src': z(s.P + slack, i32), 'pair_dst': z(s.P + slack, i32), 'pair_graph': z(s.P + slack, i32),
+                  'golden32': z(s.P + slack, i32)}
+        self.pieces = torch.zeros(s.B, s.S, dtype=torch.int64, device=dev)
+        self.props = torch.zeros(s.B, 3, dtype=torch.float32, device=dev)
+        self.num_bond_type = num_bond_type
+        node_off = self.offs[0]
+        segments = ops.Segments(node_off[:-1], node_off[1:], False)      # padding rows belong to no molecule
+        compact = CompactBatch.__new__(CompactBatch)
+        compact.cx, compact.cxp, compact.cxpos = self.t['cx'], self.t['cxp'], self.t['cxpos']
+        compact.node_off, compact.pair_off = node_off, self.pair_off
+        compact.csr = ops.Csr(self.t['row_ptr'], self.t['col'], self.t['cls'])
+        compact.csr_in = ops.Csr(self.t['in_row_ptr'], self.t['in_col'], self.t['in_cls'])
+        compact.segments = segments
+        pairs = ops.PairList(self.t['pair_src'][:s.P], self.t['pair_dst'][:s.P], self.t['pair_graph'][:s.P], self.pair_off,
+                             segments)
+        pairs.live = self.pair_off[s.B:s.B + 1]                          # pairs of this batch, read on the device
+        compact._pairs, compact._golden, compact._pending = pairs, self.t['golden32'][:s.P], None
+        compact._pair_bufs = None
+        compact.num_graphs = s.B
+        self.batch = CollatedBatch()
+        self.batch.compact = compact
+        self.batch.pieces, self.batch.props, self.batch.batch_size = self.pieces, self.props, s.B
+
+
+def collate_static(dpacked, ids, static, uniforms=None, atom_pad=10, piece_pad=300, keep_prob=KEEP_PROB, generator=None):
+    """Collate molecules `ids` into the fixed-size buffers of `static` (StaticBatch).  Returns its
+    CollatedBatch (compact layout only), or None when the batch does not fit the static sizes.
+
+    Padding: atom rows beyond the batch's own V have no bonds (their CSR rows are empty) and
+    belong to no molecule, pair rows beyond the batch's own P lie behind `pairs.live` - so they
+    feed no sum, receive a zero gradient and contribute nothing to any weight gradient.  A batch
+    that would keep more than static.P pairs keeps the first static.P (by molecule order)."""
+    s = static.shapes
+    p = plan(dpacked.host, ids)
+    if p['B'] != s.B:
+        raise ValueError(f'a static batch holds {s.B} molecules, {p["B"]} given')
+    if p['V'] > s.V or p['E'] > s.E or p['Ein'] > s.Ein or p['R'] > s.R or p['S'] > s.S or p['N'] > s.N:
+        return None
+    host = static.offs_host.next()
+    host.copy_(torch.from_numpy(p['offs']))
+    static.offs.copy_(host, non_blocking=True)
+    static.offs_host.sent()
+    node_off, edge_off, inedge_off, rng_off, mol_ids = static.offs
+    dev = static.device
+    if uniforms is None:
+        uniforms = torch.rand(max(s.R, 1), dtype=torch.float64, device=dev, generator=generator)
+    elif uniforms.numel() < p['R']:
+        raise ValueError(f'{p["R"]} uniforms needed, {uniforms.numel()} given')
+    hip.collate_count(s.B, s.N, mol_ids, dpacked, rng_off, uniforms, keep_prob, static.pair_cnt, static.pair_off)
+    static.pair_off.clamp_(max=s.P)
+    t = static.t
+    t['row_ptr'].fill_(p['E'])            # padding rows: empty CSR rows behind the last edge
+    t['in_row_ptr'].fill_(p['Ein'])
+    hip.collate_fill(s.B, s.N, s.S, mol_ids, dpacked,
+                     {'node_off': node_off, 'edge_off': edge_off, 'inedge_off': inedge_off, 'rng_off': rng_off,
+                      'pair_off': static.pair_off},
+                     p['E'], uniforms, keep_prob, atom_pad, piece_pad, static.num_bond_type,
+                     {'pieces': static.pieces, 'props': static.props}, t)
+    static.batch.num_uniforms = p['R']
+    return static.batch

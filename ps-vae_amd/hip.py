@@ -72,7 +72,7 @@ _SIGNATURES = {
     'psvae_pair_gather_fwd': (_c_int, [_c_int, _c_int, _c_int, _p, _c_int, _p, _c_int, _p, _p, _p, _p, _p]),
     'psvae_pair_gather_bwd': (_c_int, [_c_int, _c_int, _c_int, _p, _p, _p, _p, _p, _p, _p, _c_int, _p, _c_int, _p]),
     'psvae_link_ce_workspace_bytes': (_c_size, [_c_int]),
-    'psvae_link_ce_fwd': (_c_int, [_c_int, _c_int, _c_int, _p, _c_int, _p, _p, _p, _p, _p, _p, _p, _p, _c_size, _p]),
+    'psvae_link_ce_fwd': (_c_int, [_c_int, _c_int, _c_int, _p, _c_int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _c_size, _p]),
     'psvae_link_ce_bwd_input': (_c_int, [_c_int, _c_int, _c_int, _p, _p, _p, _p, _c_int, _p]),
     'psvae_pair_combine_bwd': (_c_int, [_c_int, _c_int, _p, _c_int, _p, _c_int, _c_int, _p, _p, _p, _p, _p, _p, _c_int, _p,
                                         _c_int, _p]),
@@ -84,6 +84,7 @@ _SIGNATURES = {
     'psvae_embed_trans_fwd': (_c_int, [_c_int, _c_int, _p, _p, _p, _c_int, _c_int, _c_int, _p, _p, _c_int, _p]),
     'psvae_clip_adam_workspace_bytes': (_c_size, [_c_ll]),
     'psvae_clip_adam_step': (_c_int, [_c_ll, _p, _p, _p, _p, _c_f32, _c_f32] + [_c_f64] * 5 + [_c_int, _c_int, _p, _p, _c_size, _p]),
+    'psvae_clip_adam_step_dev': (_c_int, [_c_ll, _p, _p, _p, _p, _c_f32, _c_f32] + [_c_f64] * 4 + [_p, _c_int, _p, _p, _c_size, _p]),
     'psvae_assemble_links_workspace_bytes': (_c_size, [_c_int]),
     'psvae_assemble_links': (_c_int, [_c_int, _c_int] + [_p] * 12 + [_c_int, _c_int] + [_p] * 5 + [_c_size, _p]),
 }
@@ -539,9 +540,10 @@ def pair_combine_bwd(g_out, out, relu, src, dst, pair_ptr, node_begin, node_end,
     ops().pair_combine_bwd(g_out, out, relu, src, dst, pair_ptr, node_begin, node_end, g_ab, g_c)
 
 
-def link_ce_fwd(hid, W, b, golden, logits, dlogits, loss, n_correct):
+def link_ce_fwd(hid, W, b, golden, logits, dlogits, loss, n_correct, live=None):
+    """live: device int32 [1]: only the first live[0] rows are pairs (the rest pads a fixed-size buffer)."""
     _count()
-    ops().link_ce_fwd(hid, W, b, golden, logits, dlogits, loss, n_correct)
+    ops().link_ce_fwd(hid, W, b, golden, live, logits, dlogits, loss, n_correct)
 
 
 def link_ce_bwd_input(dlogits, W, g_loss, g_hid):
@@ -620,9 +622,16 @@ def collate_fill(B, N, S, mol_ids, packed, offs, E, uniforms, keep_prob, atom_pa
     _check(rc, 'psvae_collate_fill')
 
 
+def adam_step_scalars(step, lr, betas=(0.9, 0.999)):
+    """(lr / (1 - beta1^t), sqrt(1 - beta2^t)) in double: the two step-dependent scalars of the update."""
+    return lr / (1.0 - betas[0] ** step), (1.0 - betas[1] ** step) ** 0.5
+
+
 def clip_adam_step(p, g, m, v, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0,
-                   max_norm=0.0, write_grad=True, norm_out=None):
-    """Scale + global-norm clip + Adam on flat f32 buffers (psvae_clip_adam_step)."""
+                   max_norm=0.0, write_grad=True, norm_out=None, step_scalars=None):
+    """Scale + global-norm clip + Adam on flat f32 buffers (psvae_clip_adam_step).  step_scalars: a
+    device float32 [2] holding adam_step_scalars(step, lr) - then `step` and `lr` are not read and
+    nothing step-dependent is a kernel argument (psvae_clip_adam_step_dev: for HIP graph replay)."""
     L = lib()
     n = p.numel()
     if not (g.numel() == m.numel() == v.numel() == n):
@@ -630,6 +639,12 @@ def clip_adam_step(p, g, m, v, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_de
     nbytes = L.psvae_clip_adam_workspace_bytes(n)
     ws = workspace(nbytes, p.device) if nbytes else None
     f = torch.float32
+    if step_scalars is not None:
+        _check(L.psvae_clip_adam_step_dev(n, ptr(p, f), ptr(g, f), ptr(m, f), ptr(v, f), float(grad_scale),
+                                          float(max_norm or 0.0), float(betas[0]), float(betas[1]), float(eps),
+                                          float(weight_decay), ptr(step_scalars, f), 1 if write_grad else 0,
+                                          ptr(norm_out, f), ptr(ws), nbytes, _stream()), 'psvae_clip_adam_step_dev')
+        return
     _check(L.psvae_clip_adam_step(n, ptr(p, f), ptr(g, f), ptr(m, f), ptr(v, f), float(grad_scale), float(max_norm or 0.0),
                                   float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
                                   int(step), 1 if write_grad else 0, ptr(norm_out, f), ptr(ws), nbytes, _stream()),

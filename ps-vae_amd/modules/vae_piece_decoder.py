@@ -140,7 +140,7 @@ class VAEPieceDecoder(nn.Module):
             weight, bias = ops.affine_merge(last.weight, last.bias, seq[-1].weight, seq[-1].bias)
             if golden is None:
                 return ops.linear(hid, weight, bias), None, None
-            loss, logits, n_ok = ops.link_ce(hid, weight, bias, golden)
+            loss, logits, n_ok = ops.link_ce(hid, weight, bias, golden, getattr(pairs, 'live', None))
             return logits, loss, n_ok
         feats = ops.pair_gather(node_embedding, z_vecs, pairs)
         if isinstance(seq, nn.Sequential) and len(seq) > 1 and isinstance(seq[-1], nn.Linear):
@@ -156,7 +156,7 @@ class VAEPieceDecoder(nn.Module):
             weight, bias = last.weight, last.bias
         if golden is None:
             return ops.linear(hid, weight, bias), None, None
-        loss, logits, n_ok = ops.link_ce(hid, weight, bias, golden)
+        loss, logits, n_ok = ops.link_ce(hid, weight, bias, golden, getattr(pairs, 'live', None))
         return logits, loss, n_ok
 
     def embed_nodes_async(self, node_x, csr):

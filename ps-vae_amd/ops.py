@@ -94,6 +94,7 @@ class PairList:
 
     def __init__(self, src, dst, graph, ptr, nodes):
         self.src, self.dst, self.graph, self.ptr, self.nodes = src, dst, graph, ptr, nodes
+        self.live = None   # device int32 [1] when the arrays are fixed-size buffers: only the first live[0] pairs count
 
     def __len__(self):
         return self.src.numel()
@@ -231,7 +232,7 @@ class _GineEncoder(Function):
     against the per-graph sums of the hidden rows."""
 
     @staticmethod
-    def forward(ctx, x_in, w0, b0, table, w1, b1, w2, b2, csr, t, only_last=False, pool=None):
+    def forward(ctx, x_in, w0, b0, table, w1, b1, w2, b2, csr, t, only_last=False, pool=None, track=True):
         """w0 None: x_in [V,H] already is node_trans' output (see embed_trans).
         only_last: return the last iterate alone (its slot of the internal buffer) - the caller that
         uses nothing else then gets a [V,H] gradient instead of a [V, t*H] one that is zero in t-1
@@ -254,7 +255,7 @@ class _GineEncoder(Function):
             hip.gemm(V, H, Din, x_in, _ld(x_in), 1, w0, 1, Din, x0, H, bias=b0)
         # The ReLU decisions of every layer's first Linear as bits (V H / 8 bytes per layer): the
         # backward gates its gradient with them instead of re-reading h
-        grad = any(ctx.needs_input_grad)
+        grad = track and any(ctx.needs_input_grad)    # (track: the caller's grad mode; inside forward it is always off)
         use_bits = V >= 32 and grad
         bits = torch.empty(t, hip.gemm_bits_words(V, H), dtype=torch.int64, device=dev) if use_bits else None
         # and those of the messages every node sends (H / 2 bytes per node and layer for C <= 4)
@@ -373,7 +374,7 @@ class _GineEncoder(Function):
         else:
             hip.gemm(H, H, V, last, 1, _ld(last), h[t - 1], H, 1, gw2, H, split_k=0, rowsum=gb2, accumulate=t > 1)
         hip.gemm(H, H, TV, gh2, 1, H, a2, H, 1, gw1, H, split_k=0, rowsum=gb1)
-        tail = (None,) * 4
+        tail = (None,) * 5
         if w0 is None:
             return (g_x0, None, None, g_table, gw1, gb1, gw2, gb2) + tail
         Din = x_in.shape[1]
@@ -391,7 +392,7 @@ def gine_encoder(x_in, w0, b0, table, w1, b1, w2, b2, csr, t, only_last=False, p
     pool (Segments that cover all rows): their sums over each graph's nodes, [B, t*H]."""
     if pool is not None and (only_last or not pool.covers_all_rows):
         raise ValueError('gine_encoder: pooling needs segments that cover all rows, and all iterates')
-    return _GineEncoder.apply(x_in, w0, b0, table, w1, b1, w2, b2, csr, t, only_last, pool)
+    return _GineEncoder.apply(x_in, w0, b0, table, w1, b1, w2, b2, csr, t, only_last, pool, torch.is_grad_enabled())
 
 
 # ------------------------------------------------------------------------ embed_atom
@@ -847,7 +848,7 @@ def affine_merge(w_last, b_last, w_out, b_out):
 # ------------------------------------------------------------------------ link loss
 class _LinkCe(Function):
     @staticmethod
-    def forward(ctx, hid, weight, bias, golden):
+    def forward(ctx, hid, weight, bias, golden, live=None):
         hid2 = _rows2d(hid)
         w = weight.contiguous()
         P, C = hid2.shape[0], w.shape[0]
@@ -856,7 +857,7 @@ class _LinkCe(Function):
         dlogits = torch.empty(P, C, dtype=torch.float32, device=dev)
         loss = torch.empty((), dtype=torch.float32, device=dev)
         n_correct = torch.empty((), dtype=torch.int32, device=dev)
-        hip.link_ce_fwd(hid2, w, bias, golden, logits, dlogits, loss, n_correct)
+        hip.link_ce_fwd(hid2, w, bias, golden, logits, dlogits, loss, n_correct, live=live)
         ctx.save_for_backward(hid2, w, dlogits)
         ctx.has_bias = bias is not None
         ctx.mark_non_differentiable(logits, n_correct)
@@ -885,13 +886,14 @@ class _LinkCe(Function):
             hip.colsum(dlogits, gb)
         if want_gb:
             gb = gb * g_loss
-        return g_hid, gw, gb, None
+        return g_hid, gw, gb, None, None
 
 
-def link_ce(hid, weight, bias, golden):
+def link_ce(hid, weight, bias, golden, live=None):
     """Last Linear of the link predictor + mean 4-class cross-entropy.
-    Returns (loss, logits [P,C], n_correct)."""
-    return _LinkCe.apply(hid, weight, bias, golden)
+    Returns (loss, logits [P,C], n_correct).  live (device int32 [1]): only the first live[0] rows are
+    pairs, the rest pads a fixed-size buffer and takes no part."""
+    return _LinkCe.apply(hid, weight, bias, golden, live)
 
 
 # ------------------------------------------------------------------------ token loss with an ignored label

@@ -35,14 +35,18 @@ class FlatAdam(torch.optim.Optimizer):
         self.sync.zero_grad()
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, step_scalars=None):
+        """step_scalars (device float32 [2] = hip.adam_step_scalars(step number, lr)): the update takes
+        its step-dependent numbers from device memory and `self.steps` is left to the caller - the form
+        a step recorded in a HIP graph needs (graph_step.GraphedTrainStep)."""
         loss = closure() if closure is not None else None
         sync, group = self.sync, self.param_groups[0]
         sync.sync(average=False)
-        self.steps += 1
+        if step_scalars is None:
+            self.steps += 1
         hip.clip_adam_step(sync.flat_params, sync.flat, self.exp_avg, self.exp_avg_sq, self.steps, group['lr'],
                            group['betas'], group['eps'], group['weight_decay'], grad_scale=1.0 / sync.world,
-                           max_norm=self.max_norm, write_grad=True, norm_out=self.grad_norm)
+                           max_norm=self.max_norm, write_grad=True, norm_out=self.grad_norm, step_scalars=step_scalars)
         return loss
 
     def state_dict(self):

@@ -37,6 +37,12 @@ class PSVAEModel(nn.Module):
         # compact path only; PSVAE_STREAMS=1 keeps everything on the current stream
         self.two_streams = os.environ.get('PSVAE_STREAMS', '2') != '1'
         self.two_streams_min_nodes = 32768   # atoms in the batch from which the fork pays (measured)
+        # A step recorded in a HIP graph (graph_step.GraphedTrainStep) cannot take values that change
+        # from step to step as Python numbers: the KL weight then comes from this device scalar
+        self.beta_tensor = None
+        # and the noise of the reparameterisation can be supplied in a fixed tensor [>= batch, latent_dim]
+        # (None: drawn with torch.randn_like, as the reference does)
+        self.eps_tensor = None
 
     @property
     def device(self):
@@ -78,6 +84,9 @@ class PSVAEModel(nn.Module):
 
     def forward(self, batch, return_accu=False, eps=None):
         compact = getattr(batch, 'compact', None)
+        if eps is None and self.eps_tensor is not None:
+            n = compact.num_graphs if compact is not None else batch['x'].shape[0]
+            eps = self.eps_tensor[:n]
         if compact is not None:
             # ids + tables instead of the embedded rows [V, D]: both encoders take their first layer from them
             x = self.decoder.embedded_ids(compact.cx, compact.cxp, compact.cxpos)
@@ -139,7 +148,7 @@ class PSVAEModel(nn.Module):
 
     def weighted_loss(self, pred_loss, rec_loss, kl_loss):
         alpha = self.config['alpha']
-        beta = self.cal_beta()
+        beta = self.cal_beta() if self.beta_tensor is None else self.beta_tensor
         return alpha * rec_loss + (1 - alpha) * pred_loss + beta * kl_loss
 
     def training_step(self, batch, batch_idx):
