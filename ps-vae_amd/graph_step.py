@@ -78,6 +78,8 @@ class GraphedTrainStep:
         model = self.model
         if model.beta_tensor is None:
             model.beta_tensor = self.beta
+        if len(ids) != self.shapes.B:          # the short last batch of an epoch
+            return self._eager(ids)
         batch = collate_static(self.dataset.dpacked, ids, self.static, uniforms=uniforms, generator=self.generator,
                                **self.pads)
         if batch is None:

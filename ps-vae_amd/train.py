@@ -153,9 +153,12 @@ def evaluate(model, loader, hook, name):
 
 
 def fit(model, train_loader, valid_loader=None, test_loader=None, max_epochs=6, grad_clip=10.0, patience=3,
-        finish_anneal=0, monitor='val_loss', save_dir=None, on_step=None):
+        finish_anneal=0, monitor='val_loss', save_dir=None, on_step=None, graph_steps=False):
     """Returns a dict: epochs run, global_step, per-epoch monitor values and learning rates,
-    best checkpoint path, test loss."""
+    best checkpoint path, test loss.
+    graph_steps (one process, the fused optimiser, a loader over a BPEMolDataset): every full training
+    batch is stepped by replaying the step recorded in a HIP graph (graph_step.GraphedTrainStep) -
+    what small batches such as the reference's 32 need to keep the GPU busy."""
     optimizers, schedulers = model.configure_optimizers()
     opt = optimizers[0]
     fused_tail = hasattr(opt, 'sync')          # optim.FlatAdam: exchange + clip + Adam in step()
@@ -165,6 +168,12 @@ def fit(model, train_loader, valid_loader=None, test_loader=None, max_epochs=6, 
     if not fused_tail and _world() > 1:        # a stock optimiser: the same flat all-reduce, ahead of the clipping
         from .dist import FlatGradSync
         exchange = FlatGradSync(model.parameters())
+    graphed = None
+    if graph_steps:
+        if not fused_tail or _world() > 1 or not hasattr(train_loader, 'order'):
+            raise ValueError('graph_steps needs one process, optim.FlatAdam and a loader of this package')
+        from .graph_step import GraphedTrainStep
+        graphed = GraphedTrainStep(model, opt, train_loader.dataset, train_loader.batch_size)
     stopper = VAEEarlyStopping(finish_anneal, patience=patience)
     ckpt = ModelCheckpoint(save_dir, monitor, write=_rank() == 0)
     history = {'monitor': [], 'lr': [], 'stopped_early': False}
@@ -172,7 +181,14 @@ def fit(model, train_loader, valid_loader=None, test_loader=None, max_epochs=6, 
     epoch = 0
     for epoch in range(max_epochs):
         history['lr'].append(opt.param_groups[0]['lr'])
-        for i, batch in enumerate(train_loader):
+        if graphed is not None:
+            order = train_loader.order()
+            train_loader.epoch += 1
+            for i in range(0, len(order), train_loader.batch_size):
+                loss = graphed.step(order[i:i + train_loader.batch_size])
+                if on_step is not None:
+                    on_step(model, loss)
+        for i, batch in enumerate(train_loader if graphed is None else ()):
             if exchange is not None:
                 exchange.zero_grad()
             else:
@@ -245,6 +261,9 @@ def parse(argv=None):
     ap.add_argument('--piece_embedding_dim', type=int, default=100)
     ap.add_argument('--pos_embedding_dim', type=int, default=50)
     ap.add_argument('--piece_hidden_dim', type=int, default=200)
+    ap.add_argument('--no_graph_step', action='store_true',
+                    help='launch the training step kernel by kernel even where it could be replayed from a HIP graph '
+                         '(one process, at most 256 molecules per batch)')
     return ap.parse_args(argv)
 
 
@@ -285,7 +304,8 @@ def main(argv=None):
     model = PSVAEModel(build_config(args, tokenizer), tokenizer).to(device)
     torch.manual_seed(2021 + rank)           # per-rank streams for the latent noise
     result = fit(model, *loaders, max_epochs=args.epochs, grad_clip=args.grad_clip, patience=args.patience,
-                 finish_anneal=finish_anneal_step(args), monitor=args.monitor, save_dir=args.save_dir)
+                 finish_anneal=finish_anneal_step(args), monitor=args.monitor, save_dir=args.save_dir,
+                 graph_steps=world == 1 and per_rank <= 256 and not args.no_graph_step)
     if rank == 0:
         print(result)
     if world > 1:

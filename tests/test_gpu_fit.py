@@ -8,7 +8,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def test_fit_trains_validates_checkpoints_and_reloads(tokenizer, tmp_path):
+@pytest.mark.parametrize('graph_steps', [False, True])
+def test_fit_trains_validates_checkpoints_and_reloads(tokenizer, tmp_path, graph_steps):
     from ps_vae_amd import train
     from ps_vae_amd.data.bpe_dataset import get_dataloader
     from ps_vae_amd.data.synthetic import synthetic_step1
@@ -25,7 +26,7 @@ def test_fit_trains_validates_checkpoints_and_reloads(tokenizer, tmp_path):
                for a, b, s in ((0, 32 * 6, True), (32 * 6, 32 * 8, False), (32 * 8, 32 * 9, False))]
     losses = []
     hist = train.fit(model, *loaders, max_epochs=3, grad_clip=10.0, patience=3, save_dir=str(tmp_path),
-                     on_step=lambda m, loss: losses.append(float(loss)))
+                     on_step=lambda m, loss: losses.append(float(loss)), graph_steps=graph_steps)
     assert hist['epochs'] == 3 and hist['global_step'] == 18 and len(losses) == 18
     assert hist['lr'] == pytest.approx([1e-3, 5e-4, 1e-3 / 3])              # LambdaLR(1 / (epoch + 1))
     assert np.isfinite(losses).all() and np.mean(losses[-6:]) < np.mean(losses[:6])
