@@ -234,11 +234,15 @@ class _Prof:
             PROFILE.setdefault(self.name, []).append((self.e0, e1, self.work, self.tag))
 
 
-def aggregate_bytes(V, E, H, backward=False):
+def aggregate_bytes(V, E, H, backward=False, mask_bytes=0):
     """Algorithmic bytes of one GINE aggregation: per directed edge one neighbour row (4H),
     its int32 column index and 1-byte bond class; per node its own row in, the output row out
-    and an int32 row pointer; the backward also reads the saved input row."""
-    return E * (4 * H + 5) + V * (8 * H + 4) + (V * 4 * H if backward else 0)
+    and an int32 row pointer.  The backward that recomputes the ReLU decisions also reads the saved
+    input row (V * 4H); the one that takes them as bits reads `mask_bytes` per node instead."""
+    extra = 0
+    if backward:
+        extra = V * mask_bytes if mask_bytes else V * 4 * H
+    return E * (4 * H + 5) + V * (8 * H + 4) + extra
 
 
 def gemm_shape_table(prof):
@@ -379,7 +383,8 @@ def gine_aggregate_bwd_bits(mask, C, g, t_row_ptr, t_col, t_cls, g_x, g_table, a
     seg_add [graphs, H] / node_graph [V]: a per-graph row added to every node of the graph."""
     V, H = g.shape
     _count()
-    with _Prof('gine_aggregate_bwd_kernel', aggregate_bytes(V, t_col.numel(), H, backward=True)):
+    with _Prof('gine_aggregate_bwd_kernel', aggregate_bytes(V, t_col.numel(), H, backward=True,
+                                                            mask_bytes=mask.shape[-1] * mask.element_size())):
         ops().gine_aggregate_bwd_bits(mask, C, g, t_row_ptr, t_col, t_cls, add, seg_add, node_graph, g_x, g_table,
                                       accumulate_table)
 

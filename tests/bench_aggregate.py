@@ -49,9 +49,30 @@ def timed(fn, iters=20):
     return e0.elapsed_time(e1) / iters * 1e3
 
 
+flush_src = torch.randn(160 << 20, device=dev)     # 640 MB: more than the last-level cache holds
+flush_dst = torch.empty_like(flush_src)
+
+
+def timed_cold(fn, iters=12):
+    """Each call after 1.3 GB of unrelated traffic (what the products between two aggregations of a
+    training step do to the caches), timed by its own pair of events."""
+    total = 0.0
+    for _ in range(iters + 2):
+        flush_dst.copy_(flush_src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        if _ >= 2:
+            total += e0.elapsed_time(e1)
+    return total / iters * 1e3
+
+
 E = csr.col.numel()
 fb, bb = hip.aggregate_bytes(V, E, H), hip.aggregate_bytes(V, E, H, backward=True)
 rows = [
+    ('plain copy out = x (yardstick)', lambda: out.copy_(x), 2 * V * H * 4),
     ('fwd plain', lambda: hip.gine_aggregate_fwd(x, table, csr.row_ptr, csr.col, csr.cls, out), fb),
     ('fwd + bits', lambda: hip.gine_aggregate_fwd_bits(x, table, csr.row_ptr, csr.col, csr.cls, out, mask), fb),
     ('bwd from x, add', lambda: hip.gine_aggregate_bwd(x, table, g, csr.t_row_ptr, csr.t_col, csr.t_cls, gx, gt, add=add), bb),
@@ -62,5 +83,5 @@ rows = [
 ]
 print(f'V={V} E={E} H={H}')
 for name, fn, nbytes in rows:
-    us = timed(fn)
-    print(f'{name:28s} {us:8.1f} us   {nbytes / us / 1e3:7.0f} GB/s of algorithmic bytes ({nbytes / 8e3 / us:.3f} of 8 TB/s)')
+    us, cold = timed(fn), timed_cold(fn)
+    print(f'{name:32s} {us:8.1f} us (cold caches {cold:6.1f} us)   {nbytes / us / 1e3:7.0f} GB/s of algorithmic bytes ({nbytes / us / 8e6:.3f} of 8 TB/s)')

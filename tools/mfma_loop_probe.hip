@@ -3,7 +3,11 @@
 // k-tile.  MODE bits: 1 = operands read from LDS (6 ds_read_b32 per step, one step ahead), 2 = two barriers per
 // k-tile, 4 = 36 ds_write_b32 per thread and k-tile (staging), 8 = 9 global 16-byte loads per thread and k-tile,
 // 16 = the same 9 x 16 bytes per thread straight to LDS (global_load_lds_dwordx4, two LDS stages, no staging
-// registers, each wave waits for its own loads before the barrier), 32 = staging with ds_write_b128.
+// registers, each wave waits for its own loads before the barrier), 32 = staging with ds_write_b128,
+// 64 = operands read by ds_read_b64 from row-major tiles of 34-word rows (a lane's two registers feed two
+// consecutive MFMAs: lanes 0-31 hold k = 4j, 4j+1, lanes 32-63 k = 4j+2, 4j+3; 6 reads per 10 MFMAs),
+// 128 = staging into those tiles with 18 ds_write_b64 per thread and k-tile, 256 (with 8) = the global loads one
+// per k-step behind that step's MFMAs instead of nine in a row at the top of the k-tile.
 // Build: hipcc --offload-arch=gfx950 -O3 tools/mfma_loop_probe.hip -o exp_libs/mfma_loop_probe
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -25,6 +29,9 @@ __global__ __launch_bounds__(256, 3) void probe(float *out, const float4 *src, i
     float4 stage[9];
     for (int i = 0; i < 9; ++i) stage[i] = make_float4(tid, i, 1.f, 2.f);
     long long gq = ((long long)blockIdx.x * 256 + tid) % src_quads;
+    constexpr int RS = BK + 2;                       // row-major tiles: 34-word rows, conflict-free b64 reads
+    const float2 *ar2 = reinterpret_cast<const float2 *>(As + (wave * 32 + l31) * RS + 2 * lhi);
+    const float2 *br2 = reinterpret_cast<const float2 *>(Bs + l31 * RS + 2 * lhi);
     float a_reg = 0.5f + lane, b_reg[TN];
     for (int j = 0; j < TN; ++j) b_reg[j] = 0.25f * (j + 1);
     for (int t = 0; t < tiles; ++t) {
@@ -45,6 +52,20 @@ __global__ __launch_bounds__(256, 3) void probe(float *out, const float4 *src, i
 #pragma unroll
             for (int i = 0; i < 9; ++i) *reinterpret_cast<float4 *>(As + ((tid + 256 * i) * 4) % (BK * A_STRIDE - 4) / 4 * 4) = stage[i];
         }
+        if (MODE & 128) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int item = tid + 256 * i;
+                float2 *d = reinterpret_cast<float2 *>(As + (item / 8) * RS + 4 * (item % 8));
+                d[0] = make_float2(stage[i].x, stage[i].y), d[1] = make_float2(stage[i].z, stage[i].w);
+            }
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int item = tid + 256 * i;
+                float2 *d = reinterpret_cast<float2 *>(Bs + (item / 8) * RS + 4 * (item % 8));
+                d[0] = make_float2(stage[4 + i].x, stage[4 + i].y), d[1] = make_float2(stage[4 + i].z, stage[4 + i].w);
+            }
+        }
         if (MODE & 16) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -59,13 +80,54 @@ __global__ __launch_bounds__(256, 3) void probe(float *out, const float4 *src, i
                 if (gq >= src_quads) gq -= src_quads;
             }
         }
-        if (MODE & 8) {
+#define PROBE_LOAD(i)                                                                                  \
+    do {                                                                                               \
+        if ((i) < 4) {                                                                                 \
+            stage[i] = src[gq];                                                                        \
+            gq += 256 * 768;                                                                           \
+            if (gq >= src_quads) gq -= src_quads;                                                      \
+        } else {                                                                                       \
+            stage[i] = src[((t % 10) * 5 + (i) - 4) * 256 + tid];                                      \
+        }                                                                                              \
+    } while (0)
+        if ((MODE & 8) && !(MODE & 256)) {
 #pragma unroll
             for (int i = 0; i < 9; ++i) {
-                stage[i] = src[gq];
-                gq += 256 * 768;
-                if (gq >= src_quads) gq -= src_quads;
+                if (i < 4) {                      // the A panel streams from HBM: 16 KiB per workgroup and k-tile
+                    stage[i] = src[gq];
+                    gq += 256 * 768;
+                    if (gq >= src_quads) gq -= src_quads;
+                } else {                          // the B tile is the same 400 KB for every workgroup: L2 hits
+                    stage[i] = src[((t % 10) * 5 + i - 4) * 256 + tid];
+                }
             }
+        }
+        if (MODE & 64) {
+            float2 a2 = ar2[0], b2[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b2[j] = br2[j * 32 * RS / 2];
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 4) {
+                float2 a2n = a2, b2n[TN];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b2n[j] = b2[j];
+                if (kk + 4 < BK) {
+                    a2n = ar2[(kk + 4) / 2];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) b2n[j] = br2[j * 32 * RS / 2 + (kk + 4) / 2];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.x, b2[j].x, acc[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.y, b2[j].y, acc[j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                a2 = a2n;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b2[j] = b2n[j];
+            }
+            if (MODE & 2) __syncthreads();
+            continue;
         }
         float a_cur = (MODE & 1) ? ar[0] : a_reg, b_cur[TN];
 #pragma unroll
@@ -84,6 +146,10 @@ __global__ __launch_bounds__(256, 3) void probe(float *out, const float4 *src, i
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur[j], acc[j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+            if ((MODE & 256) && kk / 2 < 9) {    // this k-tile's global loads spread over the k-steps, each behind five queued MFMAs
+                PROBE_LOAD(kk / 2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             a_cur = a_nxt;
 #pragma unroll
             for (int j = 0; j < TN; ++j) b_cur[j] = b_nxt[j];
@@ -127,6 +193,13 @@ int main() {
         run<19>(out, src, quads, blocks);
         run<35>(out, src, quads, blocks);
         run<43>(out, src, quads, blocks);
+        run<64>(out, src, quads, blocks);
+        run<66>(out, src, quads, blocks);
+        run<64 + 2 + 128>(out, src, quads, blocks);
+        run<64 + 2 + 128 + 8>(out, src, quads, blocks);
+        run<64 + 2 + 4 + 8>(out, src, quads, blocks);
+        run<256 + 11>(out, src, quads, blocks);
+        run<256 + 15>(out, src, quads, blocks);
     }
     return 0;
 }
