@@ -295,6 +295,10 @@ def roofline_report(prof, hbm_peak_gbs, mfma_peak_tflops, traffic=None):
     if hb:
         out['roofline_hbm'] = hb
     if hbb:
+        hbb['work_note'] = ('bytes the kernel has to move: one gathered gradient row, index and class per edge; own '
+                            'gradient row in, result row out, row pointer and (when the ReLU decisions arrive as bits) '
+                            'the mask words per node - not the 4H bytes of an x row per node that a backward '
+                            'recomputing the decisions would read')
         out['roofline_hbm_bwd'] = hbb
     out['event_ms_total'] = {k: round(v['ms'], 3) for k, v in sorted(groups.items())}
     return out
