@@ -457,8 +457,8 @@ int psvae_link_infer(int P, int C, const float *logits, float add_edge_th, int n
  * T[x] + T[n_atom + xp] + T[n_atom + n_piece + xq], with T [n_atom + n_piece + n_pos, H] =
  * the three tables multiplied by the matching column blocks of the weight (bias folded into the
  * atom rows by the caller).  Writes out [V,H] (row stride ld_out, H and ld_out multiples of 4);
- * ids outside their table are clamped into it.  The gradient of T is indicator^T g:
- * psvae_embed_atom_onehot + psvae_gemm_f32.
+ * ids outside their table are clamped into it.  The gradient of T is the sum of the rows of g per
+ * table row: psvae_key_sort over the three id columns (once per batch) + psvae_keyed_row_sum.
  * ---------------------------------------------------------------------------------- */
 int psvae_embed_trans_fwd(int V, int H, const int32_t *x, const int32_t *xp, const int32_t *xq,
                           int n_atom, int n_piece, int n_pos, const float *T, float *out,
