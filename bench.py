@@ -49,11 +49,35 @@ def parse():
     return ap.parse_args()
 
 
+REAL_DIR = os.path.join(ROOT, 'tests', 'golden', 'real')
+
+
+def real_tokenizer(shape):
+    from ps_vae_amd.utils.tokenizer import Tokenizer
+    return Tokenizer(os.path.join(REAL_DIR, f'{shape}_vocab_300.txt'))
+
+
 def make_dataset(num, seed, tok, device, shape='zinc'):
     import ps_vae_amd  # noqa: F401
     from ps_vae_amd.data.bpe_dataset import BPEMolDataset
     from ps_vae_amd.data.packed import PackedMolecules
     from ps_vae_amd.data.synthetic import synthetic_step1
+    if shape.endswith('_real'):
+        # real molecules: 2048 SMILES lines of the reference's data files (tests/golden/real/), read, kekulised
+        # and tokenised without RDKit against a vocabulary mined from those same lines; `tok` is that vocabulary
+        from ps_vae_amd.data import mol_bpe
+        cache = f'/tmp/psvae_{shape}_{seed}.npz'
+        if os.path.exists(cache):
+            return BPEMolDataset(None, tok, device=device, data=PackedMolecules.load(cache))
+        np.random.seed(seed)
+        with open(os.path.join(REAL_DIR, f'{shape[:-5]}_2048.smi')) as f:
+            data = [mol_bpe.process_step1(line.strip(), tok) for line in f if line.strip()]
+        packed = PackedMolecules.from_step1(data)
+        try:
+            packed.save(cache)
+        except OSError:
+            pass
+        return BPEMolDataset(None, tok, device=device, data=packed)
     cache = f'/tmp/psvae_synth_{shape}_{num}_{seed}.npz'
     if os.path.exists(cache):
         packed = PackedMolecules.load(cache)
@@ -153,7 +177,7 @@ def small_batch_record(model_factory, tok, shape, B, steps, warmup, dev):
     ordinary step of the same model) over the step time."""
     from ps_vae_amd import hip
     from ps_vae_amd.graph_step import GraphedTrainStep
-    dataset = make_dataset(64 * B, 7, tok, dev, shape=shape)
+    dataset = make_dataset(64 * B, 7, tok, dev, shape=shape)   # (real molecules: the 2048 of the fixture file)
     rng = np.random.default_rng(3)
 
     def timed(step_fn, n):
@@ -238,10 +262,25 @@ def generation_record(model, dev, n_mol=10000, reps=3):
             dec.infer_links_batch(z, g['x'], g['x_pieces'], g['x_pos'], g['node_off'], g['csr_in'], g['block0'], 0.5)
         torch.cuda.synchronize()
         t_link = (time.perf_counter() - t0) / reps
+        # matrix-product flops of one link prediction, and the time of those kernels alone (event brackets)
+        from ps_vae_amd import hip
+        hip.PROFILE = prof = {}
+        dec.infer_links_batch(z, g['x'], g['x_pieces'], g['x_pos'], g['node_off'], g['csr_in'], g['block0'], 0.5)
+        torch.cuda.synchronize()
+        hip.PROFILE = None
+    flops = sum(it[2] for it in prof.get('gemm_f32_kernel', []))
+    gemm_ms = sum(it[0].elapsed_time(it[1]) for it in prof.get('gemm_f32_kernel', []))
     pairs = int(links['conf'].numel())
+    tflops = flops / t_link / 1e12
     return {'molecules': n_mol, 'atoms': int(g['x'].numel()), 'candidate_pairs': pairs,
             'value': round(n_mol / t_all, 1), 'unit': 'molecules/s', 'ms_total': round(t_all * 1e3, 2),
             'link_prediction_ms': round(t_link * 1e3, 2), 'link_prediction_pairs_per_s': round(pairs / t_link, 1),
+            'roofline': {'bound': 'mfma', 'scope': 'link prediction (all kernels and gaps), matrix-product flops only',
+                         'achieved': round(tflops, 2), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': round(tflops / MFMA_F32_PEAK_TFLOPS, 4), 'gemm_gflop': round(flops / 1e9, 1),
+                         'gemm_kernels_alone_ms': round(gemm_ms, 3),
+                         'gemm_kernels_alone_frac': round(flops / (gemm_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4) if gemm_ms else None,
+                         'traffic': None},
             'note': 'random-init weights, synthetic 300-piece vocabulary; sampling + expansion + link prediction '
                     'over all cross-fragment pairs + greedy assembly'}
 
@@ -397,6 +436,20 @@ def main():
             del dataset
             out['b32'] = small_batch_record(factory, tok, 'zinc', 32, 200, 30, dev)
             out['b32_qm9'] = small_batch_record(factory, tok, 'qm9', 32, 200, 30, dev)
+            for shape in ('zinc', 'qm9'):          # configs[1] / configs[0] on real molecules
+                rtok = real_tokenizer(shape)
+
+                def real_factory():
+                    torch.manual_seed(2021)
+                    m = PSVAEModel(build_config(cfg_args, rtok), rtok).to(dev)
+                    (o,), _ = m.configure_optimizers()
+                    o.max_norm = cfg_args.grad_clip
+                    return m, o
+                rec = small_batch_record(real_factory, rtok, shape + '_real', 32, 200, 30, dev)
+                rec['data'] = (f'real molecules: 2048 lines of the reference\'s data/{"qm9/train" if shape == "qm9" else "zinc250k/valid"}'
+                               '.txt, preprocessed without RDKit (own kekulisation, 300-piece vocabulary mined from the '
+                               'same lines, property scores zero)')
+                out[f'b32_{shape}_real'] = rec
             out['infer_10k'] = generation_record(model, dev)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(tok, args.cpu_batch, args.cpu_steps, B, args.cpu_full_steps)

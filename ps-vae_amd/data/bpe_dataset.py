@@ -1,9 +1,11 @@
 """BPEMolDataset / get_dataloader with the reference's names
 (src/data/bpe_dataset.py:19-187); collation runs on the GPU.
 
-The dataset holds the molecules in the packed layout (data/packed.py) on the device.
-process_step1 (RDKit -> raw dict, :30-54) is outside the path: a dataset is built from a
-list of process_step1 dicts or from a packed .npz file."""
+The dataset holds the molecules in the packed layout (data/packed.py) on the device.  It is built
+from a list of process_step1 dicts, a packed .npz file, the reference's processed_data.pkl, or -
+like the reference, :157-171 - from a SMILES file through process_step1 (data.mol_bpe: the same
+tokenisation on plain graphs instead of RDKit molecules; the three RDKit property scores are
+not computed and read as zeros unless supplied)."""
 import os
 import random
 
@@ -20,8 +22,9 @@ class BPEMolDataset(torch.utils.data.Dataset):
         path of a SMILES file whose directory holds the dataset cache 'processed_data.pkl' (a
         torch-saved list of process_step1 dicts, read with weights_only=True).  The packed
         form of that cache is kept beside it as 'processed_data.npz' and preferred when present.
-        `data` passes a list of process_step1 dicts (or a PackedMolecules) directly.
-        Building the cache from SMILES (process, :157-171) needs RDKit and is not done here."""
+        `data` passes a list of process_step1 dicts (or a PackedMolecules) directly.  With neither
+        cache present the SMILES file itself is processed (process, :157-171) and the packed cache
+        written beside it."""
         super(BPEMolDataset, self).__init__()
         self.tokenizer = tokenizer
         self.device = torch.device(device)
@@ -40,8 +43,11 @@ class BPEMolDataset(torch.utils.data.Dataset):
                     except OSError:
                         pass
                 else:
-                    raise FileNotFoundError(f'neither {cache} nor {pkl} exists; creating the cache from '
-                                            f'{fname} is process_step1 (RDKit), outside this package')
+                    self.packed = PackedMolecules.from_step1(self.process(fname))
+                    try:
+                        self.packed.save(cache)
+                    except OSError:
+                        pass
         if data is not None:
             self.packed = data if isinstance(data, PackedMolecules) else PackedMolecules.from_step1(data)
         self._check_ids()
@@ -57,6 +63,24 @@ class BPEMolDataset(torch.utils.data.Dataset):
         for what, arr, n in checks:
             if arr.size and (int(arr.min()) < 0 or int(arr.max()) >= n):
                 raise ValueError(f'{what} outside [0, {n}): {int(arr.min())} .. {int(arr.max())}')
+
+    @staticmethod
+    def process_step1(mol, tokenizer, props=None):
+        """Reference :30-54: a molecule (SMILES or utils.molgraph.Mol) to the raw dict
+        {x, edge_index, edge_attr, props, pieces, groups}."""
+        from . import mol_bpe
+        return mol_bpe.process_step1(mol, tokenizer, props)
+
+    def process(self, fname):
+        """Reference :157-171: one process_step1 dict per readable SMILES line of `fname`."""
+        from ..utils import molgraph
+        data_list = []
+        with open(fname, 'r') as fin:
+            for line in fin:
+                mol = molgraph.smiles2molecule(line.strip())
+                if mol is not None and len(mol):
+                    data_list.append(self.process_step1(mol, self.tokenizer))
+        return data_list
 
     @staticmethod
     def process_step2(data, tokenizer):

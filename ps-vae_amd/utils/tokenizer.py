@@ -1,6 +1,6 @@
-"""Vocabulary-file Tokenizer surface needed by the hot path (src/data/mol_bpe.py:156-249):
-special-token layout and id lookups.  Tokenising a molecule (the greedy principal-subgraph
-merge, :175-222) needs RDKit canonical SMILES and is outside the path."""
+"""The reference's Tokenizer (src/data/mol_bpe.py:156-249): vocabulary file, special-token layout,
+id lookups, and tokenising a molecule (the greedy principal-subgraph merge, :175-222, in
+data.mol_bpe on the plain graphs of utils.molgraph instead of RDKit molecules)."""
 import numpy as np
 
 from .chem_vocab import GeneralVocab, cnt_atom
@@ -70,6 +70,7 @@ class Tokenizer:
         stores, see vocab_state).  Without either, `num_pieces` synthetic pieces are created."""
         self.vocab_dict, self.idx2piece, self.piece2idx = {}, [], {}
         self._fragments = None
+        self._canonical = None
         if pieces is not None:
             for smi, atom_num, freq in pieces:
                 self.vocab_dict[smi] = (int(atom_num), int(freq))
@@ -101,8 +102,25 @@ class Tokenizer:
         n = len(self.idx2piece) - 2     # without <pad> and <s>
         return [[smi, self.vocab_dict[smi][0], self.vocab_dict[smi][1]] for smi in self.idx2piece[:n]]
 
+    def canonical_pieces(self):
+        """{canonical name of a piece's graph: (its SMILES in this vocabulary, its frequency)}: the
+        vocabulary re-keyed by utils.molgraph.canonical_smiles, so that pieces are recognised whatever
+        tool wrote the file's SMILES.  Pieces that cannot be read as kekulised SMILES are left out."""
+        if self._canonical is None:
+            from . import molgraph
+            table = {}
+            for smi in self.idx2piece[:len(self.idx2piece) - 2]:
+                mol = molgraph.smiles2molecule(smi)
+                if mol is not None:
+                    table.setdefault(molgraph.canonical_smiles(mol.symbols, mol.bonds), (smi, self.vocab_dict[smi][1]))
+            self._canonical = table
+        return self._canonical
+
     def tokenize(self, mol, return_idx=False):
-        raise NotImplementedError('principal-subgraph tokenisation needs RDKit (src/data/mol_bpe.py:175-222)')
+        """mol: SMILES or utils.molgraph.Mol.  [(piece SMILES, atom ids)] between two end tokens, pieces
+        in shuffled order (np.random), or (piece ids, atom id groups) with return_idx."""
+        from ..data import mol_bpe
+        return mol_bpe.tokenize(self, mol, return_idx)
 
     __call__ = tokenize
 

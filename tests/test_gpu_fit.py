@@ -46,3 +46,32 @@ def test_fit_trains_validates_checkpoints_and_reloads(tokenizer, tmp_path, graph
     again = train.evaluate(fresh, loaders[1], 'validation_step', 'val_loss')
     # (eps of the reparameterisation is drawn afresh, so the KL-free part agrees only loosely)
     assert abs(again - hist['best_score']) <= 0.05 * abs(hist['best_score'])
+
+
+def test_main_trains_on_real_qm9_smiles(tmp_path):
+    """train.main end to end on real molecules (BASELINE.json configs[0] in small): SMILES files (lines of
+    the reference's data/qm9/train.txt, tests/golden/real/) -> process_step1 without RDKit -> packed
+    caches beside the files -> two epochs at batch 32 through the recorded step -> checkpoint ->
+    PSVAEModel.load_from_checkpoint.  The property scores are zeros (RDKit descriptors)."""
+    import os
+    from ps_vae_amd import train
+    from ps_vae_amd.pl_models import PSVAEModel
+    real = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'real')
+    with open(os.path.join(real, 'qm9_2048.smi')) as f:
+        lines = f.readlines()
+    files = {}
+    for name, a, b in (('train', 0, 512), ('valid', 512, 640), ('test', 640, 768)):
+        d = tmp_path / name                  # one directory per split: the dataset cache lives beside the file
+        d.mkdir()
+        files[name] = d / f'{name}.txt'
+        files[name].write_text(''.join(lines[a:b]))
+    np.random.seed(1)
+    result = train.main(['--train_set', str(files['train']), '--valid_set', str(files['valid']), '--test_set', str(files['test']),
+                         '--vocab', os.path.join(real, 'qm9_vocab_300.txt'), '--save_dir', str(tmp_path / 'ckpt'),
+                         '--alpha', '0.1', '--batch_size', '32', '--epochs', '2', '--shuffle'])
+    assert result['epochs'] == 2 and result['global_step'] == 32
+    assert np.isfinite(result['monitor']).all() and result['monitor'][1] < result['monitor'][0]
+    assert np.isfinite(result['test_loss'])
+    assert (tmp_path / 'train' / 'processed_data.npz').exists()
+    model = PSVAEModel.load_from_checkpoint(result['best_path'])
+    assert model.tokenizer.num_piece_type() == 302

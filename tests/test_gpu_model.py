@@ -450,14 +450,34 @@ def test_batch_32_train_step_against_oracle(tokenizer, shape):
     """One full training step at batch 32, default widths, on QM9-shaped molecules (at most 9
     atoms: the reference's own CPU configuration) and ZINC-shaped ones: GPU collation bit-exact
     against the oracle's, every loss, every parameter gradient, the clipped gradient norm and
-    every parameter after the Adam step against the oracle in float64 (a gradient may instead
-    be as close to float64 as twice the fp32 CPU oracle's own distance: summation order)."""
+    every parameter after the Adam step against the oracle in float64."""
+    from ps_vae_amd.data.synthetic import synthetic_step1
+    batch_32_step_against_oracle(tokenizer, synthetic_step1(32, seed=55, shape=shape))
+
+
+@pytest.mark.parametrize('name', ['qm9', 'zinc'])
+def test_batch_32_train_step_on_real_molecules(name):
+    """The same step on REAL molecules: the first 32 SMILES of the reference's data/qm9/train.txt and
+    data/zinc250k/valid.txt (tests/golden/real/), read, kekulised and tokenised without RDKit
+    (data.mol_bpe) against a 300-piece vocabulary mined from the first 2048 lines of the same file.
+    The preprocessing is not pinned by the reference (no RDKit, no vocabulary file ships with it); the
+    kernels are held to the oracle on whatever molecules it yields.  Property scores are zeros."""
+    import os
+    from ps_vae_amd.data import mol_bpe
+    from ps_vae_amd.utils.tokenizer import Tokenizer
+    real = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'real')
+    tok = Tokenizer(os.path.join(real, f'{name}_vocab_300.txt'))
+    with open(os.path.join(real, f'{name}_2048.smi')) as f:
+        smiles = [line.strip() for line in f][:32]
+    np.random.seed(4)                       # the order of a molecule's pieces is shuffled (mol_bpe.py:214)
+    batch_32_step_against_oracle(tok, [mol_bpe.process_step1(s, tok) for s in smiles])
+
+
+def batch_32_step_against_oracle(tokenizer, step1):
     import copy
     from ps_vae_amd.data.collate import collate_packed
     from ps_vae_amd.data.packed import PackedMolecules
-    from ps_vae_amd.data.synthetic import synthetic_step1
-    B = 32
-    step1 = synthetic_step1(B, seed=55, shape=shape)
+    B = len(step1)
     uniforms = np.random.default_rng(8).random(1500 * B)
     want_batch, used = collate_ref.collate(step1, uniforms, piece_pad=tokenizer.pad_idx())
     cfg = model_ref.default_config(tokenizer)
