@@ -14,7 +14,9 @@ data in device memory, never a kernel argument:
     into small device tensors before every replay.
 
 A batch that does not fit the fixed sizes (a tail event, see StaticShapes.for_dataset) is stepped the
-ordinary way.  One process, one GPU: the gradient exchange of a multi-GPU run is not recorded."""
+ordinary way.  One process, one GPU: the gradient exchange of a multi-GPU run is not recorded.
+The recording keeps the model's two-stream fork (encoder beside decoder GNN + piece LM) as parallel
+branches of the graph."""
 import torch
 
 from . import hip
@@ -28,6 +30,12 @@ class GraphedTrainStep:
         if not hasattr(optimizer, 'sync') or optimizer.sync.world != 1:
             raise ValueError('GraphedTrainStep needs optim.FlatAdam in a single process')
         self.model, self.opt, self.dataset = model, optimizer, dataset
+        # The decoder's message passing and the piece LM go to the model's second stream whatever the batch
+        # size: in a recording the fork costs the host nothing and the two branches run side by side
+        # (measured at batch 32: 2.17 -> 1.67 ms per step ZINC-shaped, 1.72 -> 1.21 ms QM9-shaped).  The
+        # warm-up steps fork as well, so that the second stream's workspaces exist before the recording.
+        if model.two_streams:
+            model.two_streams_min_nodes = 0
         self.device = model.device
         self.shapes = shapes or StaticShapes.for_dataset(dataset.packed, batch_size, sigmas)
         tok = dataset.tokenizer
