@@ -77,6 +77,10 @@ class FlatGradSync:
         size; optim.FlatAdam passes False and folds the division into its update kernel.
         One process: pack only."""
         self.pack()
+        self.exchange(average)
+
+    def exchange(self, average=True):
+        """The collective alone, on gradients that are already packed."""
         if self.world > 1:
             if self.flat.is_cuda and dist.get_backend(self.group) == 'gloo':
                 # rehearsals of the multi-rank path without RCCL: stage through host memory

@@ -14,7 +14,9 @@ data in device memory, never a kernel argument:
     into small device tensors before every replay.
 
 A batch that does not fit the fixed sizes (a tail event, see StaticShapes.for_dataset) is stepped the
-ordinary way.  One process, one GPU: the gradient exchange of a multi-GPU run is not recorded.
+ordinary way.  In a multi-GPU run (one process per GPU) the recording ends where the gradients are
+packed into the flat buffer; the all-reduce and the two optimiser kernels follow it as ordinary calls,
+so every step has exactly one collective on every rank whichever way the rank stepped.
 The recording keeps the model's two-stream fork (encoder beside decoder GNN + piece LM) as parallel
 branches of the graph."""
 import torch
@@ -27,8 +29,9 @@ class GraphedTrainStep:
     def __init__(self, model, optimizer, dataset, batch_size, sigmas=4.0, shapes=None, warmup=3, generator=None):
         """model: PSVAEModel on a GPU; optimizer: optim.FlatAdam over its parameters (its max_norm
         is the clipping threshold); dataset: BPEMolDataset (packed molecules on the device)."""
-        if not hasattr(optimizer, 'sync') or optimizer.sync.world != 1:
-            raise ValueError('GraphedTrainStep needs optim.FlatAdam in a single process')
+        if not hasattr(optimizer, 'sync'):
+            raise ValueError('GraphedTrainStep needs optim.FlatAdam')
+        self.exchange_outside = optimizer.sync.world > 1
         self.model, self.opt, self.dataset = model, optimizer, dataset
         # The decoder's message passing and the piece LM go to the model's second stream whatever the batch
         # size: in a recording the fork costs the host nothing and the two branches run side by side
@@ -67,8 +70,16 @@ class GraphedTrainStep:
         self.opt.zero_grad()
         loss = self.model.training_step(batch, 0)
         loss.backward()
-        self.opt.step(step_scalars=self.scalars)
+        if self.exchange_outside:
+            self.opt.sync.pack()
+        else:
+            self.opt.step(step_scalars=self.scalars)
         return loss.detach()
+
+    def _tail(self):
+        """What follows the recording in a multi-GPU run: all-reduce, clip, Adam."""
+        if self.exchange_outside:
+            self.opt.step(step_scalars=self.scalars, packed=True)
 
     def _eager(self, ids):
         """The ordinary step for a batch beyond the fixed sizes."""
@@ -76,6 +87,7 @@ class GraphedTrainStep:
         batch = self.dataset.collate_ids(ids)
         self._scalars_to_device()
         loss = self._body(batch)
+        self._tail()
         self.opt.steps += 1
         self.model.global_step += 1
         return loss
@@ -101,12 +113,14 @@ class GraphedTrainStep:
             if self.graph is None:
                 torch.cuda.synchronize(self.device)
                 self.graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph):
+                # (several ranks: the process group's watchdog thread may touch the GPU while this thread records)
+                with torch.cuda.graph(self.graph, capture_error_mode='thread_local' if self.exchange_outside else 'global'):
                     self.loss = self._body(batch)
                 # (recording runs nothing: the replay below is this step)
             self.graph.replay()
             self.replays += 1
             loss = self.loss
+        self._tail()
         self.opt.steps += 1
         model.global_step += 1
         return loss

@@ -35,13 +35,18 @@ class FlatAdam(torch.optim.Optimizer):
         self.sync.zero_grad()
 
     @torch.no_grad()
-    def step(self, closure=None, step_scalars=None):
+    def step(self, closure=None, step_scalars=None, packed=False):
         """step_scalars (device float32 [2] = hip.adam_step_scalars(step number, lr)): the update takes
         its step-dependent numbers from device memory and `self.steps` is left to the caller - the form
-        a step recorded in a HIP graph needs (graph_step.GraphedTrainStep)."""
+        a step recorded in a HIP graph needs (graph_step.GraphedTrainStep).  packed: the gradients
+        already sit in the flat buffer (sync.pack() was part of a recording); only the collective and
+        the update remain."""
         loss = closure() if closure is not None else None
         sync, group = self.sync, self.param_groups[0]
-        sync.sync(average=False)
+        if packed:
+            sync.exchange(average=False)
+        else:
+            sync.sync(average=False)
         if step_scalars is None:
             self.steps += 1
         hip.clip_adam_step(sync.flat_params, sync.flat, self.exp_avg, self.exp_avg_sq, self.steps, group['lr'],

@@ -156,9 +156,10 @@ def fit(model, train_loader, valid_loader=None, test_loader=None, max_epochs=6, 
         finish_anneal=0, monitor='val_loss', save_dir=None, on_step=None, graph_steps=False):
     """Returns a dict: epochs run, global_step, per-epoch monitor values and learning rates,
     best checkpoint path, test loss.
-    graph_steps (one process, the fused optimiser, a loader over a BPEMolDataset): every full training
-    batch is stepped by replaying the step recorded in a HIP graph (graph_step.GraphedTrainStep) -
-    what small batches such as the reference's 32 need to keep the GPU busy."""
+    graph_steps (the fused optimiser, a loader over a BPEMolDataset): every full training batch is
+    stepped by replaying the step recorded in a HIP graph (graph_step.GraphedTrainStep) - what small
+    batches such as the reference's 32 need to keep the GPU busy.  With several ranks the recording
+    covers forward, backward and gradient packing; the all-reduce and the optimiser follow it."""
     optimizers, schedulers = model.configure_optimizers()
     opt = optimizers[0]
     fused_tail = hasattr(opt, 'sync')          # optim.FlatAdam: exchange + clip + Adam in step()
@@ -170,8 +171,8 @@ def fit(model, train_loader, valid_loader=None, test_loader=None, max_epochs=6, 
         exchange = FlatGradSync(model.parameters())
     graphed = None
     if graph_steps:
-        if not fused_tail or _world() > 1 or not hasattr(train_loader, 'order'):
-            raise ValueError('graph_steps needs one process, optim.FlatAdam and a loader of this package')
+        if not fused_tail or not hasattr(train_loader, 'order'):
+            raise ValueError('graph_steps needs optim.FlatAdam and a loader of this package')
         from .graph_step import GraphedTrainStep
         graphed = GraphedTrainStep(model, opt, train_loader.dataset, train_loader.batch_size)
     stopper = VAEEarlyStopping(finish_anneal, patience=patience)
@@ -216,6 +217,8 @@ def fit(model, train_loader, valid_loader=None, test_loader=None, max_epochs=6, 
             break
     history.update(epochs=epoch + 1, global_step=model.global_step, best_path=ckpt.best_path,
                    best_score=ckpt.best_score)
+    if graphed is not None:
+        history.update(graph_replays=graphed.replays, ordinary_steps=model.global_step - graphed.replays)
     if test_loader is not None:
         history['test_loss'] = evaluate(model, test_loader, 'test_step', 'test_loss')
     return history
@@ -263,7 +266,7 @@ def parse(argv=None):
     ap.add_argument('--piece_hidden_dim', type=int, default=200)
     ap.add_argument('--no_graph_step', action='store_true',
                     help='launch the training step kernel by kernel even where it could be replayed from a HIP graph '
-                         '(one process, at most 256 molecules per batch)')
+                         '(at most 256 molecules per rank and batch)')
     return ap.parse_args(argv)
 
 
@@ -305,7 +308,7 @@ def main(argv=None):
     torch.manual_seed(2021 + rank)           # per-rank streams for the latent noise
     result = fit(model, *loaders, max_epochs=args.epochs, grad_clip=args.grad_clip, patience=args.patience,
                  finish_anneal=finish_anneal_step(args), monitor=args.monitor, save_dir=args.save_dir,
-                 graph_steps=world == 1 and per_rank <= 256 and not args.no_graph_step)
+                 graph_steps=per_rank <= 256 and not args.no_graph_step)
     if rank == 0:
         print(result)
     if world > 1:

@@ -98,7 +98,7 @@ def test_two_ranks_on_one_gpu_stay_identical(tmp_path):
     assert res[0]['warnings'] == [] and res[1]['warnings'] == []
 
 
-def _fit_rank(rank, port, out_dir):
+def _fit_rank(rank, port, out_dir, graph_steps=False):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD),
                       LOCAL_RANK='0')                  # both ranks drive GPU 0
     import torch.distributed as dist
@@ -122,23 +122,28 @@ def _fit_rank(rank, port, out_dir):
     order = loaders[0].order                            # record the ids of every epoch as the loader deals them
     loaders[0].order = lambda: seen.append(order().tolist()) or np.asarray(seen[-1])
     torch.manual_seed(2021 + rank)
-    hist = train.fit(model, *loaders, max_epochs=2, grad_clip=10.0, save_dir=os.path.join(out_dir, 'ckpt'))
+    hist = train.fit(model, *loaders, max_epochs=2, grad_clip=10.0, save_dir=os.path.join(out_dir, 'ckpt'),
+                     graph_steps=graph_steps)
     torch.cuda.synchronize()
     torch.save({'params': torch.cat([p.detach().flatten().cpu() for p in model.parameters()]), 'seen': seen,
-                'monitor': hist['monitor'], 'steps': hist['global_step'], 'best_path': hist['best_path']},
+                'monitor': hist['monitor'], 'steps': hist['global_step'], 'best_path': hist['best_path'],
+                'replays': hist.get('graph_replays', 0)},
                os.path.join(out_dir, f'fit{rank}.pt'))
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.gpu
-def test_fit_two_ranks_on_one_gpu(tmp_path):
+@pytest.mark.parametrize('graph_steps', [False, True])
+def test_fit_two_ranks_on_one_gpu(tmp_path, graph_steps):
     """ps_vae_amd.train.fit with the HIP model as two ranks (gloo) on one GPU: disjoint shares of equal
     length per epoch, identical parameters after two epochs, one reduced validation value, one
-    checkpoint (rank 0's) from which PSVAEModel.load_from_checkpoint rebuilds the model."""
+    checkpoint (rank 0's) from which PSVAEModel.load_from_checkpoint rebuilds the model.
+    graph_steps: full batches through the recorded step (forward, backward and packing replayed, the
+    all-reduce and the optimiser behind it); the short last batch of an epoch the ordinary way."""
     ctx = multiprocessing.get_context('forkserver')
     port = _free_port()
-    procs = [ctx.Process(target=_fit_rank, args=(r, port, str(tmp_path))) for r in range(WORLD)]
+    procs = [ctx.Process(target=_fit_rank, args=(r, port, str(tmp_path), graph_steps)) for r in range(WORLD)]
     for p in procs:
         p.start()
     for p in procs:
@@ -151,6 +156,8 @@ def test_fit_two_ranks_on_one_gpu(tmp_path):
     res = [torch.load(os.path.join(tmp_path, f'fit{r}.pt'), weights_only=True) for r in range(WORLD)]
     assert torch.equal(res[0]['params'], res[1]['params'])
     assert res[0]['steps'] == res[1]['steps'] == 2 * 4                   # ceil(51 / 16) steps per epoch
+    # three warm-up steps and the two short batches run the ordinary way, the other three are replays
+    assert res[0]['replays'] == res[1]['replays'] == (3 if graph_steps else 0)
     assert res[0]['monitor'] == res[1]['monitor'] and np.isfinite(res[0]['monitor']).all()
     for e in range(2):
         a, b = res[0]['seen'][e], res[1]['seen'][e]

@@ -28,6 +28,7 @@ def test_fit_trains_validates_checkpoints_and_reloads(tokenizer, tmp_path, graph
     hist = train.fit(model, *loaders, max_epochs=3, grad_clip=10.0, patience=3, save_dir=str(tmp_path),
                      on_step=lambda m, loss: losses.append(float(loss)), graph_steps=graph_steps)
     assert hist['epochs'] == 3 and hist['global_step'] == 18 and len(losses) == 18
+    assert hist.get('graph_replays', 0) == (15 if graph_steps else 0)       # all but the three warm-up steps
     assert hist['lr'] == pytest.approx([1e-3, 5e-4, 1e-3 / 3])              # LambdaLR(1 / (epoch + 1))
     assert np.isfinite(losses).all() and np.mean(losses[-6:]) < np.mean(losses[:6])
     assert len(hist['monitor']) == 3 and np.isfinite(hist['monitor']).all() and np.isfinite(hist['test_loss'])
