@@ -444,6 +444,24 @@ int psvae_token_ce_fwd(int R, int V, const float *logits, int64_t ld, const int3
                        void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * One step of the piece sampling loop of generation, after the vocabulary projection
+ * (src/modules/vae_piece_decoder.py:139-158): per molecule b that is still active, logits[b][pad] and
+ * (first_step) logits[b][end] count as -inf, probs = softmax(logits[b] / temperature) and
+ *   next = min(#{i : cdf[i] <= uniforms[b] * cdf[last]}, last),  cdf = running sum of probs in index
+ *   order, last = largest index of positive probability
+ * (the inverse-CDF form of torch.multinomial(probs, 1) from a supplied uniform number); then
+ * out[b] = next, length[b] += 1, atoms[b] += piece_atoms[next], and the molecule becomes inactive when
+ * next == end, atoms[b] > max_atom_num or length[b] == max_pos; cur[b] = next while it stays active,
+ * end otherwise.  An inactive molecule writes out[b] = pad, cur[b] = end and keeps its counters.
+ * logits [B, V] rows ld_logits apart; uniforms and out are columns of [B, *] arrays (element b at
+ * b * ld_uniforms / b * ld_out); active [B] bytes, atoms / length [B] int32, out / cur int64.
+ * ---------------------------------------------------------------------------------- */
+int psvae_piece_draw(int B, int V, const float *logits, int64_t ld_logits, float temperature, const float *uniforms,
+                     int64_t ld_uniforms, int pad_idx, int end_idx, int first_step, const int32_t *piece_atoms,
+                     int max_atom_num, int max_pos, uint8_t *active, int32_t *atoms, int32_t *length,
+                     int64_t *out, int64_t ld_out, int64_t *cur, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * Inference link prediction (src/modules/vae_piece_decoder.py:233-240):
  * prob = softmax(logits[p]); conf[p] = max prob, etype[p] = argmax (first maximum);
  * keep[p] = conf[p] >= add_edge_th && etype[p] != none_bond.

@@ -81,6 +81,8 @@ _SIGNATURES = {
     'psvae_token_ce_workspace_bytes': (_c_size, [_c_int]),
     'psvae_token_ce_fwd': (_c_int, [_c_int, _c_int, _p, _c_i64, _p, _c_int, _p, _c_i64, _p, _p, _p, _c_size, _p]),
     'psvae_link_infer': (_c_int, [_c_int, _c_int, _p, _c_f32, _c_int, _p, _p, _p, _p]),
+    'psvae_piece_draw': (_c_int, [_c_int, _c_int, _p, _c_i64, _c_f32, _p, _c_i64, _c_int, _c_int, _c_int, _p, _c_int, _c_int,
+                                  _p, _p, _p, _p, _c_i64, _p, _p]),
     'psvae_embed_trans_fwd': (_c_int, [_c_int, _c_int, _p, _p, _p, _c_int, _c_int, _c_int, _p, _p, _c_int, _p]),
     'psvae_clip_adam_workspace_bytes': (_c_size, [_c_ll]),
     'psvae_clip_adam_step': (_c_int, [_c_ll, _p, _p, _p, _p, _c_f32, _c_f32] + [_c_f64] * 5 + [_c_int, _c_int, _p, _p, _c_size, _p]),
@@ -565,6 +567,20 @@ def token_ce_fwd(logits, gold, ignore_index, n_classes, dlogits, loss, counts):
     rows are wide: columns from n_classes on are zeroed), loss f32[2], counts i32[2]."""
     _count()
     ops().token_ce_fwd(logits, gold, int(ignore_index), int(n_classes), dlogits, loss, counts)
+
+
+def piece_draw(logits, temperature, uniforms_col, pad, end, first_step, piece_atoms, max_atom_num, max_pos, active, atoms,
+               length, out_col, cur):
+    """psvae_piece_draw: one sampling step for all molecules (uniforms_col / out_col: column views [B] of the
+    [B, max_pos] arrays)."""
+    B, V = logits.shape
+    _count()
+    _check(lib().psvae_piece_draw(B, V, ptr(logits, torch.float32), logits.stride(0), float(temperature),
+                                  ptr(uniforms_col, torch.float32), uniforms_col.stride(0) if B > 1 else 1, int(pad), int(end),
+                                  int(bool(first_step)), ptr(piece_atoms, torch.int32), int(max_atom_num), int(max_pos),
+                                  ptr(active, torch.uint8), ptr(atoms, torch.int32), ptr(length, torch.int32),
+                                  ptr(out_col, torch.int64), out_col.stride(0) if B > 1 else 1, ptr(cur, torch.int64),
+                                  _stream()), 'psvae_piece_draw')
 
 
 def link_infer(logits, add_edge_th, none_bond, conf, etype, keep):

@@ -290,37 +290,23 @@ class VAEPieceDecoder(nn.Module):
         gates = torch.empty(B, 3 * H, device=dev)
         cur = torch.full((B,), end, dtype=torch.int64, device=dev)
         out = torch.full((B, max_pos), pad, dtype=torch.int64, device=dev)
-        length = torch.zeros(B, dtype=torch.int64, device=dev)
-        atoms = torch.zeros(B, dtype=torch.int64, device=dev)
-        active = torch.ones(B, dtype=torch.bool, device=dev)
-        V = tok.num_piece_type()
-        col_ids = torch.arange(V, device=dev)[None, :]
+        length = torch.zeros(B, dtype=torch.int32, device=dev)
+        atoms = torch.zeros(B, dtype=torch.int32, device=dev)
+        active = torch.ones(B, dtype=torch.uint8, device=dev)
+        cnt = cnt.to(torch.int32)
         for t in range(max_pos):
             emb = self.piece_embedding(cur).contiguous()
             hip.gemm(B, 3 * H, E, emb, E, 1, w_ih, 1, E, gi, 3 * H, bias=rnn.bias_ih_l0)
             hip.gemm(B, 3 * H, H, h, H, 1, w_hh, 1, H, gh, 3 * H, bias=rnn.bias_hh_l0)
             hip.gru_cell_fwd(gi, gh, h, h_next, gates)
             logits = run_linear(self.to_vocab, h_next)
-            logits[:, pad] = float('-inf')
-            if t == 0:
-                logits[:, end] = float('-inf')
-            probs = torch.softmax(logits / temperature, dim=-1)
-            # first index whose cumulative probability exceeds u * total, never beyond the last
-            # entry of positive probability: an entry of probability zero (pad, the end token at
-            # t == 0) cannot be drawn, as with torch.multinomial
-            cdf = torch.cumsum(probs, dim=-1)
-            last = ((probs > 0) * col_ids).max(dim=-1).values
-            idx = torch.minimum((cdf <= uniforms[:, t:t + 1] * cdf[:, -1:]).sum(dim=-1), last)
-            idx = torch.where(active, idx, torch.full_like(idx, pad))
-            out[:, t] = idx
-            length += active
-            atoms += torch.where(active, cnt[idx], torch.zeros_like(atoms))
-            stop = (idx == end) | (atoms > max_atom_num) | (length == max_pos)
-            active &= ~stop
+            # pad / first-step end masks, softmax(logits / T), the draw and the state update: one kernel
+            hip.piece_draw(logits, temperature, uniforms[:, t], pad, end, t == 0, cnt, max_atom_num, max_pos, active, atoms,
+                           length, out[:, t], cur)
             h, h_next = h_next, h
-            cur = torch.where(active, idx, torch.full_like(idx, end))
             if t % 8 == 7 and not bool(active.any()):
                 break
+        length = length.to(torch.int64)
         lengths = (length - 1).clamp(min=0)
         keep = torch.arange(max_pos, device=dev)[None, :] < lengths[:, None]
         return torch.where(keep, out, torch.full_like(out, pad)), lengths

@@ -1221,3 +1221,56 @@ def test_token_ce_all_rows_ignored_is_nan():
     gold = torch.full((9,), 3, dtype=torch.int32, device=d)
     loss, counts = hip_ops.token_ce(logits, gold, 3)
     assert torch.isnan(loss).item() and counts.tolist() == [0, 0]
+
+
+# ------------------------------------------------------------------ piece draw (generation)
+@pytest.mark.parametrize('B,V,temperature,first', [(1, 7, 1.0, True), (1000, 302, 1.0, False), (513, 302, 0.7, True),
+                                                    (200, 1500, 1.3, False)])
+def test_piece_draw_against_the_elementwise_form(B, V, temperature, first):
+    """psvae_piece_draw against the chain of torch operations it replaces (masks, softmax, running sum,
+    inverse-CDF pick, counters): the same pick wherever the threshold is not within rounding of an entry
+    of the running sum, and the same state for every molecule whose pick agrees."""
+    from ps_vae_amd import hip
+    d = dev()
+    g = torch.Generator().manual_seed(B + V)
+    logits = (torch.randn(B, V, generator=g) * 3).to(d)
+    logits[::7, 3:40] = -1e30                                   # rows with classes of zero probability
+    u = torch.rand(B, 5, generator=g).to(d)
+    pad, end = V - 2, V - 1
+    cnt = torch.randint(0, 9, (V,), generator=g, dtype=torch.int32).to(d)
+    cnt[pad:] = 0
+    active0 = (torch.rand(B, generator=g) < 0.8).to(d)
+    atoms0 = torch.randint(0, 40, (B,), generator=g, dtype=torch.int32).to(d)
+    length0 = torch.randint(0, 50, (B,), generator=g, dtype=torch.int32).to(d)
+    max_atom, max_pos = 38, 50
+    # the element-wise form
+    lg = logits.clone()
+    lg[:, pad] = float('-inf')
+    if first:
+        lg[:, end] = float('-inf')
+    probs = torch.softmax(lg / temperature, dim=-1)
+    cdf = torch.cumsum(probs, dim=-1)
+    last = ((probs > 0) * torch.arange(V, device=d)[None, :]).max(dim=-1).values
+    thr = u[:, 2:3] * cdf[:, -1:]
+    idx = torch.minimum((cdf <= thr).sum(dim=-1), last)
+    margin = ((cdf - thr).abs() / cdf[:, -1:]).min(dim=-1).values       # distance of the threshold from the nearest entry
+    idx = torch.where(active0, idx, torch.full_like(idx, pad))
+    want_len = length0 + active0.int()
+    want_atoms = atoms0 + torch.where(active0, cnt[idx], torch.zeros_like(atoms0))
+    stop = (idx == end) | (want_atoms > max_atom) | (want_len == max_pos)
+    want_active = active0 & ~stop
+    want_cur = torch.where(want_active, idx, torch.full_like(idx, end))
+    # the kernel
+    active, atoms, length = active0.to(torch.uint8).clone(), atoms0.clone(), length0.clone()
+    out = torch.full((B, 5), -1, dtype=torch.int64, device=d)
+    cur = torch.full((B,), -1, dtype=torch.int64, device=d)
+    hip.piece_draw(logits, temperature, u[:, 2], pad, end, first, cnt, max_atom, max_pos, active, atoms, length, out[:, 2], cur)
+    same = out[:, 2] == idx
+    clear = margin > 1e-5
+    assert bool(same[clear].all()), 'a pick differs although the threshold is clear of the running sum'
+    assert int((~same).sum()) <= max(1, B // 200)
+    assert bool((out[:, [0, 1, 3, 4]] == -1).all())                      # only its own column is written
+    for got, want, what in ((active.bool(), want_active, 'active'), (atoms, want_atoms, 'atoms'), (length, want_len, 'length'),
+                            (cur, want_cur, 'cur')):
+        assert torch.equal(got[same], want[same]), what
+    assert torch.equal(logits, logits)                                   # (the logits are not modified)
