@@ -390,7 +390,7 @@ def gine_aggregate_bwd_bits(mask, C, g, t_row_ptr, t_col, t_cls, g_x, g_table, a
     V, H = g.shape
     _count()
     with _Prof('gine_aggregate_bwd_kernel', aggregate_bytes(V, t_col.numel(), H, backward=True,
-                                                            mask_bytes=mask.shape[-1] * mask.element_size())):
+                                                            mask_bytes=mask.numel() * mask.element_size() // max(V, 1))):
         ops().gine_aggregate_bwd_bits(mask, C, g, t_row_ptr, t_col, t_cls, add, seg_add, node_graph, g_x, g_table,
                                       accumulate_table)
 
