@@ -55,12 +55,43 @@ class FlatAdam(torch.optim.Optimizer):
         return loss
 
     def state_dict(self):
-        return {'steps': self.steps, 'exp_avg': self.exp_avg.clone(), 'exp_avg_sq': self.exp_avg_sq.clone(),
-                'param_groups': [{k: v for k, v in g.items() if k != 'params'} for g in self.param_groups]}
+        """The layout of torch.optim.Adam's state_dict (what a checkpoint of the reference holds and
+        torch.optim.Adam.load_state_dict reads): per parameter, in parameter order, {'step', 'exp_avg',
+        'exp_avg_sq'} with the moments shaped like the parameter, and the param_groups with their
+        parameter indices."""
+        sync, state = self.sync, {}
+        offset = 0
+        for i, p in enumerate(sync.params):
+            n = p.numel()
+            state[i] = {'step': torch.tensor(float(self.steps)),
+                        'exp_avg': self.exp_avg[offset:offset + n].view_as(p).clone(),
+                        'exp_avg_sq': self.exp_avg_sq[offset:offset + n].view_as(p).clone()}
+            offset += (n + 3) // 4 * 4
+        groups = [{k: v for k, v in g.items() if k != 'params'} for g in self.param_groups]
+        groups[0]['params'] = list(range(len(sync.params)))
+        return {'state': state, 'param_groups': groups}
 
     def load_state_dict(self, state):
-        self.steps = int(state['steps'])
-        self.exp_avg.copy_(state['exp_avg'])
-        self.exp_avg_sq.copy_(state['exp_avg_sq'])
+        """Reads the layout above (also a state_dict written by torch.optim.Adam over the same parameters)
+        and the flat layout earlier checkpoints of this package hold ({'steps', 'exp_avg', 'exp_avg_sq'})."""
+        if 'state' in state:
+            offset = 0
+            steps = 0
+            for i, p in enumerate(self.sync.params):
+                n = p.numel()
+                entry = state['state'].get(i)
+                if entry is not None:
+                    self.exp_avg[offset:offset + n].copy_(entry['exp_avg'].reshape(-1))
+                    self.exp_avg_sq[offset:offset + n].copy_(entry['exp_avg_sq'].reshape(-1))
+                    steps = max(steps, int(float(entry['step'])))
+                else:                      # a parameter that never had a gradient has no entry in torch's dict
+                    self.exp_avg[offset:offset + n].zero_()
+                    self.exp_avg_sq[offset:offset + n].zero_()
+                offset += (n + 3) // 4 * 4
+            self.steps = steps
+        else:
+            self.steps = int(state['steps'])
+            self.exp_avg.copy_(state['exp_avg'])
+            self.exp_avg_sq.copy_(state['exp_avg_sq'])
         for g, saved in zip(self.param_groups, state['param_groups']):
-            g.update(saved)
+            g.update({k: v for k, v in saved.items() if k != 'params'})

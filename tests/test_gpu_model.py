@@ -153,6 +153,28 @@ def test_flat_adam_follows_torch_adam_with_clipping():
             close(q, p, rel=2e-6, what=f'step {step} param {i}')
             if p.grad is not None:
                 close(q.grad, p.grad, rel=2e-6, what=f'step {step} clipped grad {i}')
+    # the optimiser state travels in torch.optim.Adam's own layout, both ways
+    state = opt.state_dict()
+    want = ref_opt.state_dict()
+    assert state['param_groups'][0]['params'] == want['param_groups'][0]['params'] == list(range(len(shapes)))
+    assert state['param_groups'][0]['lr'] == want['param_groups'][0]['lr'] == 5e-4
+    for i in range(len(shapes)):
+        if i == 3:
+            continue
+        assert float(state['state'][i]['step']) == float(want['state'][i]['step']) == 20
+        close(state['state'][i]['exp_avg'], want['state'][i]['exp_avg'], rel=2e-6, what=f'exp_avg {i}')
+        close(state['state'][i]['exp_avg_sq'], want['state'][i]['exp_avg_sq'], rel=2e-6, what=f'exp_avg_sq {i}')
+    stock = torch.optim.Adam([torch.nn.Parameter(q.detach().clone()) for q in mine], lr=1e-3)
+    stock.load_state_dict(state)                               # torch's Adam reads it
+    twin = FlatAdam([torch.nn.Parameter(q.detach().clone()) for q in mine], lr=1e-3, max_norm=10.0)
+    twin.load_state_dict(want)                                 # and a state written by torch's Adam is read here
+    assert twin.steps == 20 and twin.param_groups[0]['lr'] == 5e-4
+    mask = torch.ones_like(opt.exp_avg, dtype=torch.bool)
+    off = sum((torch.Size(s).numel() + 3) // 4 * 4 for s in shapes[:3])
+    mask[off:off + 4] = False                                  # (parameter 3: torch skipped its gradient-less steps)
+    close(twin.exp_avg[mask], opt.exp_avg[mask], rel=2e-6, what='moments read back from torch')
+    twin.load_state_dict(state)
+    assert torch.equal(twin.exp_avg, opt.exp_avg) and torch.equal(twin.exp_avg_sq, opt.exp_avg_sq) and twin.steps == opt.steps
 
 
 def test_default_width_model_against_reference_golden(tokenizer):
