@@ -462,6 +462,19 @@ int psvae_piece_draw(int B, int V, const float *logits, int64_t ld_logits, float
                      int64_t *out, int64_t ld_out, int64_t *cur, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * Candidate atom pairs of generated molecules (src/modules/vae_piece_decoder.py:213-222): for molecule b
+ * (atoms node_off[b] .. node_off[b+1], fragment id frag[i] per atom) the pairs (m, k), m < k, of atoms in
+ * different fragments, in row-major order.  _count writes the number per molecule; after
+ * ptr = exclusive scan of counts, _fill writes for candidate ptr[b] + j the global atom ids src / dst, the
+ * molecule id graph and the molecule-local ids m / k.  max_atoms: at least the largest molecule (it sizes the
+ * LDS stage; at most 15 360).
+ * ---------------------------------------------------------------------------------- */
+int psvae_pair_enumerate_count(int B, int max_atoms, const int32_t *node_off, const int32_t *frag, int32_t *counts,
+                               void *stream);
+int psvae_pair_enumerate_fill(int B, int max_atoms, const int32_t *node_off, const int32_t *frag, const int32_t *ptr,
+                              int32_t *src, int32_t *dst, int32_t *graph, int32_t *m, int32_t *k, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * Inference link prediction (src/modules/vae_piece_decoder.py:233-240):
  * prob = softmax(logits[p]); conf[p] = max prob, etype[p] = argmax (first maximum);
  * keep[p] = conf[p] >= add_edge_th && etype[p] != none_bond.

@@ -1,5 +1,8 @@
-// One step of the piece sampling loop of generation, after the vocabulary projection: mask, softmax,
-// draw, state update - one wave per molecule, one launch per step in place of ~18 element-wise launches.
+// Generation-side helpers.
+//
+// (1) One step of the piece sampling loop, after the vocabulary projection: mask, softmax, draw, state
+// update - one wave per molecule, one launch per step in place of ~18 element-wise launches.
+// (2) The candidate atom pairs of the generated molecules (further down).
 //
 // Reference: src/modules/vae_piece_decoder.py:139-158 (inference): logits[pad] = -inf, logits[end] = -inf
 // on the first step, probs = softmax(logits / temperature), next = torch.multinomial(probs, 1); the
@@ -104,7 +107,100 @@ __global__ __launch_bounds__(64 * WAVES) void piece_draw_kernel(int B, int V, co
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Candidate atom pairs of generated molecules (src/modules/vae_piece_decoder.py:213-222): per molecule the
+// pairs (m, k), m < k, of atoms in different fragments, in row-major order.  One workgroup per molecule;
+// the fragment ids of its atoms sit in LDS; thread m owns row m.  Two passes: count per molecule, then
+// (after a scan over the molecules on the caller's side) fill at ptr[b] + offset of row m.
+constexpr int ENUM_THREADS = 256;
+
+__device__ __forceinline__ int block_exclusive_scan(int v, int *scratch /* [ENUM_THREADS / 64 + 1] */, int *total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int up = __shfl_up(inc, d);
+        if (lane >= d) inc += up;
+    }
+    if (lane == 63) scratch[wave] = inc;
+    __syncthreads();
+    int before = 0, all = 0;
+    for (int w = 0; w < ENUM_THREADS / 64; ++w) {
+        if (w < wave) before += scratch[w];
+        all += scratch[w];
+    }
+    __syncthreads();
+    *total = all;
+    return before + inc - v;
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(ENUM_THREADS) void pair_enumerate_kernel(int B, const int32_t *__restrict__ node_off,
+                                                                      const int32_t *__restrict__ frag,
+                                                                      int32_t *__restrict__ counts,
+                                                                      const int32_t *__restrict__ ptr, int32_t *__restrict__ src,
+                                                                      int32_t *__restrict__ dst, int32_t *__restrict__ graph,
+                                                                      int32_t *__restrict__ m_out, int32_t *__restrict__ k_out) {
+    extern __shared__ int32_t s_frag[];          // [n]
+    __shared__ int scratch[ENUM_THREADS / 64 + 1];
+    const int b = blockIdx.x;
+    const int base = node_off[b], n = node_off[b + 1] - base;
+    for (int i = threadIdx.x; i < n; i += ENUM_THREADS) s_frag[i] = frag[base + i];
+    __syncthreads();
+    int running = 0;                              // candidates of the rows before this round of ENUM_THREADS rows
+    for (int m0 = 0; m0 < n; m0 += ENUM_THREADS) {
+        const int m = m0 + (int)threadIdx.x;
+        int c = 0;
+        if (m < n) {
+            const int f = s_frag[m];
+            for (int k = m + 1; k < n; ++k) c += s_frag[k] != f;
+        }
+        int round_total;
+        const int off = block_exclusive_scan(c, scratch, &round_total);
+        if (FILL && m < n && c > 0) {
+            long long o = (long long)ptr[b] + running + off;
+            const int f = s_frag[m];
+            for (int k = m + 1; k < n; ++k) {
+                if (s_frag[k] == f) continue;
+                src[o] = base + m, dst[o] = base + k, graph[o] = b, m_out[o] = m, k_out[o] = k;
+                ++o;
+            }
+        }
+        running += round_total;
+    }
+    if (!FILL && threadIdx.x == 0) counts[b] = running;
+}
+
 }  // namespace
+
+extern "C" int psvae_pair_enumerate_count(int B, int max_atoms, const int32_t *node_off, const int32_t *frag, int32_t *counts,
+                                          void *stream) {
+    const char *fn = "psvae_pair_enumerate_count";
+    PSVAE_REQUIRE(B >= 0 && max_atoms >= 0, PSVAE_EINVAL, "%s: bad sizes", fn);
+    PSVAE_REQUIRE((size_t)max_atoms * sizeof(int32_t) <= 60 * 1024, PSVAE_ETOOLARGE, "%s: a molecule of %d atoms exceeds the LDS stage", fn,
+                  max_atoms);
+    if (B == 0) return PSVAE_OK;
+    PSVAE_REQUIRE(node_off && counts && (frag || max_atoms == 0), PSVAE_EINVAL, "%s: null pointer", fn);
+    hipLaunchKernelGGL(pair_enumerate_kernel<false>, dim3(B), dim3(ENUM_THREADS), (size_t)(max_atoms > 0 ? max_atoms : 1) * sizeof(int32_t),
+                       (hipStream_t)stream, B, node_off, frag, counts, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    PSVAE_CHECK_LAUNCH(fn);
+    return PSVAE_OK;
+}
+
+extern "C" int psvae_pair_enumerate_fill(int B, int max_atoms, const int32_t *node_off, const int32_t *frag, const int32_t *ptr,
+                                         int32_t *src, int32_t *dst, int32_t *graph, int32_t *m, int32_t *k, void *stream) {
+    const char *fn = "psvae_pair_enumerate_fill";
+    PSVAE_REQUIRE(B >= 0 && max_atoms >= 0, PSVAE_EINVAL, "%s: bad sizes", fn);
+    PSVAE_REQUIRE((size_t)max_atoms * sizeof(int32_t) <= 60 * 1024, PSVAE_ETOOLARGE, "%s: a molecule of %d atoms exceeds the LDS stage", fn,
+                  max_atoms);
+    if (B == 0) return PSVAE_OK;
+    PSVAE_REQUIRE(node_off && ptr && (frag || max_atoms == 0), PSVAE_EINVAL, "%s: null pointer", fn);
+    PSVAE_REQUIRE(src && dst && graph && m && k, PSVAE_EINVAL, "%s: null output", fn);
+    hipLaunchKernelGGL(pair_enumerate_kernel<true>, dim3(B), dim3(ENUM_THREADS), (size_t)(max_atoms > 0 ? max_atoms : 1) * sizeof(int32_t),
+                       (hipStream_t)stream, B, node_off, frag, nullptr, ptr, src, dst, graph, m, k);
+    PSVAE_CHECK_LAUNCH(fn);
+    return PSVAE_OK;
+}
 
 extern "C" int psvae_piece_draw(int B, int V, const float *logits, int64_t ld_logits, float temperature, const float *uniforms,
                                 int64_t ld_uniforms, int pad_idx, int end_idx, int first_step, const int32_t *piece_atoms,

@@ -81,6 +81,8 @@ _SIGNATURES = {
     'psvae_token_ce_workspace_bytes': (_c_size, [_c_int]),
     'psvae_token_ce_fwd': (_c_int, [_c_int, _c_int, _p, _c_i64, _p, _c_int, _p, _c_i64, _p, _p, _p, _c_size, _p]),
     'psvae_link_infer': (_c_int, [_c_int, _c_int, _p, _c_f32, _c_int, _p, _p, _p, _p]),
+    'psvae_pair_enumerate_count': (_c_int, [_c_int, _c_int, _p, _p, _p, _p]),
+    'psvae_pair_enumerate_fill': (_c_int, [_c_int, _c_int, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     'psvae_piece_draw': (_c_int, [_c_int, _c_int, _p, _c_i64, _c_f32, _p, _c_i64, _c_int, _c_int, _c_int, _p, _c_int, _c_int,
                                   _p, _p, _p, _p, _c_i64, _p, _p]),
     'psvae_embed_trans_fwd': (_c_int, [_c_int, _c_int, _p, _p, _p, _c_int, _c_int, _c_int, _p, _p, _c_int, _p]),
@@ -567,6 +569,27 @@ def token_ce_fwd(logits, gold, ignore_index, n_classes, dlogits, loss, counts):
     rows are wide: columns from n_classes on are zeroed), loss f32[2], counts i32[2]."""
     _count()
     ops().token_ce_fwd(logits, gold, int(ignore_index), int(n_classes), dlogits, loss, counts)
+
+
+def pair_enumerate(node_off, frag, max_atoms):
+    """Candidate pairs of generated molecules (psvae_pair_enumerate_count / _fill): returns
+    (src, dst, graph, m, k int32 [P], ptr int32 [B + 1]).  One host read (the total) sizes the outputs."""
+    B = node_off.numel() - 1
+    dev = node_off.device
+    counts = torch.empty(max(B, 1), dtype=torch.int32, device=dev)
+    ptr_t = torch.zeros(B + 1, dtype=torch.int32, device=dev)
+    _count()
+    _check(lib().psvae_pair_enumerate_count(B, int(max_atoms), ptr(node_off, torch.int32), ptr(frag, torch.int32),
+                                            ptr(counts, torch.int32), _stream()), 'psvae_pair_enumerate_count')
+    if B > 0:
+        exclusive_scan(counts[:B], ptr_t)
+    P = int(ptr_t[-1].item()) if B > 0 else 0
+    outs = [torch.empty(P, dtype=torch.int32, device=dev) for _ in range(5)]
+    if P > 0:
+        _check(lib().psvae_pair_enumerate_fill(B, int(max_atoms), ptr(node_off, torch.int32), ptr(frag, torch.int32),
+                                               ptr(ptr_t, torch.int32), *[ptr(o, torch.int32) for o in outs], _stream()),
+               'psvae_pair_enumerate_fill')
+    return (*outs, ptr_t)
 
 
 def piece_draw(logits, temperature, uniforms_col, pad, end, first_step, piece_atoms, max_atom_num, max_pos, active, atoms,

@@ -328,25 +328,14 @@ class VAEPieceDecoder(nn.Module):
         order [Ek] (indices of the kept candidates: conf >= add_edge_th and type != None,
         grouped by molecule, confidence descending, stable) and order_ptr [B+1]."""
         dev = self.W_mean.weight.device
-        node_off = node_off.to(dev).to(torch.int64)
-        B = node_off.numel() - 1
-        n = node_off[1:] - node_off[:-1]
-        cell_off = torch.zeros(B + 1, dtype=torch.int64, device=dev)
-        cell_off[1:] = torch.cumsum(n * n, 0)
-        total = int(cell_off[-1].item())
-        graph = torch.repeat_interleave(torch.arange(B, device=dev), n * n, output_size=total)
-        local = torch.arange(total, device=dev) - cell_off[graph]
-        ng = n[graph]
-        m, k = local // ng.clamp(min=1), local % ng.clamp(min=1)
-        frag = frag.to(dev).to(torch.int64)
-        src, dst = node_off[graph] + m, node_off[graph] + k
-        sel = (m < k) & (frag[src] != frag[dst])
-        graph, m, k, src, dst = graph[sel], m[sel], k[sel], src[sel], dst[sel]
-        ptr = torch.zeros(B + 1, dtype=torch.int32, device=dev)
-        ptr[1:] = torch.cumsum(torch.bincount(graph, minlength=B), 0)
-        no32 = node_off.to(torch.int32)
-        pairs = ops.PairList(src.to(torch.int32), dst.to(torch.int32), graph.to(torch.int32), ptr,
-                             ops.Segments.from_offsets(no32))
+        no32 = node_off.to(dev).to(torch.int32).contiguous()
+        B = no32.numel() - 1
+        # candidate enumeration in two kernels (count per molecule, scan, fill): row-major (m, k), m < k, atoms
+        # in different fragments
+        max_atoms = int((no32[1:] - no32[:-1]).max().item()) if B > 0 else 0
+        src, dst, graph32, m32, k32, ptr = hip.pair_enumerate(no32, frag.to(dev).to(torch.int32).contiguous(), max_atoms)
+        graph, m, k = graph32.to(torch.int64), m32.to(torch.int64), k32.to(torch.int64)
+        pairs = ops.PairList(src, dst, graph32, ptr, ops.Segments.from_offsets(no32))
         out = {'graph': graph, 'm': m, 'n': k, 'ptr': ptr}
         P = src.numel()
         if P == 0:

@@ -1274,3 +1274,32 @@ def test_piece_draw_against_the_elementwise_form(B, V, temperature, first):
                             (cur, want_cur, 'cur')):
         assert torch.equal(got[same], want[same]), what
     assert torch.equal(logits, logits)                                   # (the logits are not modified)
+
+
+def test_pair_enumerate_against_the_masked_cells():
+    """psvae_pair_enumerate_count / _fill against the dense form (all n x n cells of every molecule, filtered):
+    same candidates in the same order, including empty molecules, single-fragment molecules and a molecule
+    larger than one round of threads."""
+    from ps_vae_amd import hip
+    d = dev()
+    rng = np.random.default_rng(2)
+    sizes = [0, 1, 5, 23, 38, 0, 300, 2, 17] + [int(v) for v in rng.integers(1, 40, size=200)]
+    node_off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    frag = np.concatenate([rng.integers(0, max(1, s // 4 + 1), size=s) for s in sizes]).astype(np.int32)
+    frag[node_off[3]:node_off[4]] = 7                      # a molecule that is one fragment: no candidate
+    want = {k: [] for k in ('src', 'dst', 'graph', 'm', 'k')}
+    ptr = [0]
+    for b, s in enumerate(sizes):
+        f = frag[node_off[b]:node_off[b + 1]]
+        m, k = np.nonzero((np.arange(s)[:, None] < np.arange(s)[None, :]) & (f[:, None] != f[None, :]))
+        want['src'] += list(node_off[b] + m), 
+        want['dst'] += list(node_off[b] + k),
+        want['graph'] += [np.full(len(m), b)]
+        want['m'] += [m]
+        want['k'] += [k]
+        ptr.append(ptr[-1] + len(m))
+    got = hip.pair_enumerate(torch.from_numpy(node_off).to(d), torch.from_numpy(frag).to(d), max(sizes))
+    assert got[5].cpu().tolist() == ptr
+    for arr, key in zip(got[:5], ('src', 'dst', 'graph', 'm', 'k')):
+        flat = np.concatenate([np.asarray(v).reshape(-1) for v in want[key]]) if want[key] else np.zeros(0)
+        assert np.array_equal(arr.cpu().numpy(), flat.astype(np.int32)), key
