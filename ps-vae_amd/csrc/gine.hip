@@ -225,8 +225,19 @@ __global__ __launch_bounds__(32 * REDUCE_GROUPS) void gine_table_reduce_kernel(i
     const int q = threadIdx.x >> 5, l = threadIdx.x & 31;
     const int i = blockIdx.x * 32 + l;
     float s = 0.f;
-    if (i < n_out)
-        for (int b = q; b < n_blocks; b += REDUCE_GROUPS) s += partial[(long long)b * n_out + i];
+    if (i < n_out) {
+        // eight slabs requested at once (a chain of dependent adds over one load each is latency-bound), summed
+        // in slab order all the same
+        int b = q;
+        for (; b + 7 * REDUCE_GROUPS < n_blocks; b += 8 * REDUCE_GROUPS) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[(long long)(b + u * REDUCE_GROUPS) * n_out + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; b < n_blocks; b += REDUCE_GROUPS) s += partial[(long long)b * n_out + i];
+    }
     sh[q][l] = s;
     __syncthreads();
     if (q == 0 && i < n_out) {
