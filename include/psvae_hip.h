@@ -220,6 +220,15 @@ int psvae_gine_aggregate_bwd_bits(int V, int H, int C, const void *mask_bits, co
                                   const float *add, int ldadd, const float *seg_add, int ld_seg_add,
                                   const int32_t *node_graph, float *g_x, int ldgx, float *g_table,
                                   int accumulate_table, void *workspace, size_t workspace_bytes, void *stream);
+/* accumulate_table of psvae_gine_aggregate_bwd_bits may be PSVAE_TABLE_PARTIALS_ONLY: the [C,H] slabs of
+ * table-gradient partials (psvae_gine_aggregate_bwd_slabs(V, H, C) of them, one per workgroup) stay in
+ * `workspace`, g_table is not touched (it may be null) and the caller sums the slabs of several calls at
+ * once with psvae_gine_table_reduce - the t layers of an encoder share one bond table, so their backward
+ * passes need one reduction, not t. */
+#define PSVAE_TABLE_PARTIALS_ONLY 2
+int psvae_gine_aggregate_bwd_slabs(int V, int H, int C);
+int psvae_gine_table_reduce(int n_slabs, int C, int H, const float *partials, float *g_table, int accumulate,
+                            void *stream);
 
 /* psvae_gine_aggregate_bwd for callers that cannot allocate.  It has no counterpart in the
  * reference; it exists for code under HIP graph capture, tight serving loops and harnesses that

@@ -345,6 +345,8 @@ static int aggregate_bwd_impl(const char *fn, int V, int H, int C, const float *
                               const void *mask = nullptr, const float *seg_add = nullptr, int ldsa = 0,
                               const int32_t *node_graph = nullptr) {
     if (V == 0) return accumulate_table ? PSVAE_OK : (int)hipMemsetAsync(g_table, 0, (size_t)C * H * sizeof(float), s_);
+    PSVAE_REQUIRE(accumulate_table == 0 || accumulate_table == 1 || accumulate_table == PSVAE_TABLE_PARTIALS_ONLY, PSVAE_EINVAL,
+                  "%s: accumulate_table must be 0, 1 or PSVAE_TABLE_PARTIALS_ONLY", fn);
     PSVAE_REQUIRE(add == nullptr || (psvae_aligned16(add) && ldadd % 4 == 0 && ldadd >= H), PSVAE_EINVAL,
                   "%s: bad `add` operand", fn);
     PSVAE_REQUIRE((mask != nullptr || (table && psvae_aligned16(table))) && t_row_ptr && g && g_x && psvae_aligned16(g) &&
@@ -368,6 +370,7 @@ static int aggregate_bwd_impl(const char *fn, int V, int H, int C, const float *
     }
 #undef PSVAE_AGG_BWD
     PSVAE_CHECK_LAUNCH(fn);
+    if (accumulate_table == PSVAE_TABLE_PARTIALS_ONLY) return PSVAE_OK;   // the caller reduces the slabs (psvae_gine_table_reduce)
     const int n_out = C * H;
     hipLaunchKernelGGL(gine_table_reduce_kernel, dim3(psvae_cdiv(n_out, 32)), dim3(32 * REDUCE_GROUPS), 0, s_, n_out,
                        s.blocks, (const float *)partial, g_table, accumulate_table);
@@ -412,6 +415,25 @@ extern "C" int psvae_gine_aggregate_bwd_graph_add(int V, int H, int C, const flo
                               node_graph);
 }
 
+extern "C" int psvae_gine_aggregate_bwd_slabs(int V, int H, int C) {
+    if (V <= 0 || H <= 0 || C <= 0) return 0;
+    return shape_for(V, H, bwd_max_blocks()).blocks;
+}
+
+// g_table (+)= the sum of n_slabs [C,H] slabs of table-gradient partials, in slab order.
+extern "C" int psvae_gine_table_reduce(int n_slabs, int C, int H, const float *partials, float *g_table, int accumulate,
+                                       void *stream) {
+    const char *fn = "psvae_gine_table_reduce";
+    PSVAE_REQUIRE(n_slabs >= 0 && C > 0 && H > 0, PSVAE_EINVAL, "%s: bad sizes", fn);
+    PSVAE_REQUIRE(g_table != nullptr && (n_slabs == 0 || partials != nullptr), PSVAE_EINVAL, "%s: null pointer", fn);
+    const int n_out = C * H;
+    if (n_slabs == 0) return accumulate ? PSVAE_OK : (int)hipMemsetAsync(g_table, 0, (size_t)n_out * sizeof(float), (hipStream_t)stream);
+    hipLaunchKernelGGL(gine_table_reduce_kernel, dim3(psvae_cdiv(n_out, 32)), dim3(32 * REDUCE_GROUPS), 0, (hipStream_t)stream,
+                       n_out, n_slabs, partials, g_table, accumulate ? 1 : 0);
+    PSVAE_CHECK_LAUNCH(fn);
+    return PSVAE_OK;
+}
+
 // The backward from the mask bits psvae_gine_aggregate_fwd_bits left behind (x and the table are not
 // read), with an optional per-graph row added to every node of its graph.
 extern "C" int psvae_gine_aggregate_bwd_bits(int V, int H, int C, const void *mask_bits, const float *g, int ldg,
@@ -424,8 +446,10 @@ extern "C" int psvae_gine_aggregate_bwd_bits(int V, int H, int C, const void *ma
     PSVAE_REQUIRE(V >= 0 && H > 0 && C > 0 && H % 4 == 0 && H / 4 <= 1024, PSVAE_EINVAL, "%s: bad sizes V=%d H=%d C=%d", fn, V,
                   H, C);
     PSVAE_REQUIRE(C <= 8, PSVAE_ETOOLARGE, "%s: at most 8 edge classes (C=%d)", fn, C);
-    PSVAE_REQUIRE(g_table != nullptr && (V == 0 || (mask_bits != nullptr && (((uintptr_t)mask_bits) & (C <= 4 ? 1u : 3u)) == 0)),
+    PSVAE_REQUIRE((g_table != nullptr || accumulate_table == PSVAE_TABLE_PARTIALS_ONLY) &&
+                      (V == 0 || (mask_bits != nullptr && (((uintptr_t)mask_bits) & (C <= 4 ? 1u : 3u)) == 0)),
                   PSVAE_EINVAL, "%s: g_table null, or mask_bits null / misaligned", fn);
+    if (V == 0 && accumulate_table == PSVAE_TABLE_PARTIALS_ONLY) return PSVAE_OK;   // no slab is written for no node
     PSVAE_REQUIRE(V == 0 || (workspace && psvae_aligned16(workspace) &&
                              workspace_bytes >= psvae_gine_aggregate_bwd_workspace_bytes(V, H, C)),
                   PSVAE_EWORKSPACE, "%s: workspace too small", fn);

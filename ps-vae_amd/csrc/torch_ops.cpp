@@ -180,11 +180,13 @@ void gine_aggregate_fwd_bits(const Tensor &x, const Tensor &table, const Tensor 
           fn);
 }
 
+// slabs (optional, float [psvae_gine_aggregate_bwd_slabs(V, H, C), C, H] contiguous): the table-gradient partials
+// are left there and g_table is not touched; gine_table_reduce sums the slabs of several calls at once.
 void gine_aggregate_bwd_bits(const Tensor &mask, int64_t C, const Tensor &g, const Tensor &t_row_ptr, const Tensor &t_col,
                              const Tensor &t_cls, const OptTensor &add, const OptTensor &seg_add, const OptTensor &node_graph,
-                             Tensor g_x, Tensor g_table, bool accumulate_table) {
+                             Tensor g_x, Tensor g_table, bool accumulate_table, const OptTensor &slabs) {
     PSVAE_ON_DEVICE("psvae::gine_aggregate_bwd_bits", p(mask), p(g), p(t_row_ptr), p(t_col), p(t_cls), p(add), p(seg_add),
-                    p(node_graph), p(g_x), p(g_table));
+                    p(node_graph), p(g_x), p(g_table), p(slabs));
     const char *fn = "psvae_gine_aggregate_bwd_bits";
     const int V = (int)g.size(0), H = (int)g.size(1);
     TORCH_CHECK(g_table.size(0) == C && g_table.size(1) == H && g_table.is_contiguous(), fn, ": g_table must be [C, H]");
@@ -192,7 +194,14 @@ void gine_aggregate_bwd_bits(const Tensor &mask, int64_t C, const Tensor &g, con
     const size_t nbytes = psvae_gine_aggregate_bwd_workspace_bytes(V, H, (int)C);
     void *ws = nullptr;
     Tensor hold;
-    if (nbytes) hold = workspace(nbytes, g, s), ws = hold.data_ptr();
+    const bool partials_only = slabs.has_value() && slabs->defined();
+    if (partials_only) {
+        TORCH_CHECK(slabs->is_cuda() && slabs->scalar_type() == at::kFloat && slabs->is_contiguous() &&
+                        (size_t)slabs->numel() * sizeof(float) >= nbytes, fn, ": slabs must be contiguous float32 [slabs, C, H]");
+        ws = slabs->data_ptr();
+    } else if (nbytes) {
+        hold = workspace(nbytes, g, s), ws = hold.data_ptr();
+    }
     const bool has_add = add.has_value() && add->defined();
     const bool has_seg = seg_add.has_value() && seg_add->defined();
     TORCH_CHECK(!has_seg || (node_graph.has_value() && node_graph->defined() && node_graph->numel() == V), fn,
@@ -202,7 +211,17 @@ void gine_aggregate_bwd_bits(const Tensor &mask, int64_t C, const Tensor &g, con
                                         has_add ? (int)row_stride(*add, fn) : H, f32(seg_add, fn),
                                         has_seg ? (int)row_stride(*seg_add, fn) : H, has_seg ? i32(*node_graph, fn) : nullptr,
                                         f32_mut(g_x, fn), (int)row_stride(g_x, fn), f32_mut(g_table, fn),
-                                        accumulate_table ? 1 : 0, ws, nbytes, s),
+                                        partials_only ? PSVAE_TABLE_PARTIALS_ONLY : (accumulate_table ? 1 : 0), ws, nbytes, s),
+          fn);
+}
+
+void gine_table_reduce(const Tensor &slabs, Tensor g_table, bool accumulate) {
+    PSVAE_ON_DEVICE("psvae::gine_table_reduce", p(slabs), p(g_table));
+    const char *fn = "psvae_gine_table_reduce";
+    TORCH_CHECK(slabs.dim() == 3 && slabs.is_contiguous() && g_table.dim() == 2 && g_table.is_contiguous() &&
+                    slabs.size(1) == g_table.size(0) && slabs.size(2) == g_table.size(1), fn, ": slabs [n, C, H], g_table [C, H]");
+    check(psvae_gine_table_reduce((int)slabs.size(0), (int)g_table.size(0), (int)g_table.size(1), f32(slabs, fn), f32_mut(g_table, fn),
+                                  accumulate ? 1 : 0, cur_stream(slabs)),
           fn);
 }
 
@@ -468,8 +487,10 @@ TORCH_LIBRARY(psvae, m) {
     m.def("gine_aggregate_fwd_bits(Tensor x, Tensor table, Tensor row_ptr, Tensor col, Tensor cls, Tensor(a!) out, "
           "Tensor(b!) mask) -> ()", &gine_aggregate_fwd_bits);
     m.def("gine_aggregate_bwd_bits(Tensor mask, int C, Tensor g, Tensor t_row_ptr, Tensor t_col, Tensor t_cls, Tensor? add, "
-          "Tensor? seg_add, Tensor? node_graph, Tensor(a!) g_x, Tensor(b!) g_table, bool accumulate_table) -> ()",
+          "Tensor? seg_add, Tensor? node_graph, Tensor(a!) g_x, Tensor(b!) g_table, bool accumulate_table, "
+          "Tensor(c!)? slabs=None) -> ()",
           &gine_aggregate_bwd_bits);
+    m.def("gine_table_reduce(Tensor slabs, Tensor(a!) g_table, bool accumulate) -> ()", &gine_table_reduce);
     m.def("graph_rows_gated(Tensor q, Tensor node_graph, Tensor gate_bits, Tensor(a!) out) -> ()", &graph_rows_gated);
     m.def("pair_combine_fwd(Tensor a, Tensor b, Tensor c, Tensor src, Tensor dst, Tensor graph, bool relu, Tensor(a!) out) -> ()",
           &pair_combine_fwd);

@@ -47,6 +47,8 @@ _SIGNATURES = {
                                                     _p, _c_int, _p, _p, _c_int, _p, _c_int, _p, _c_size, _p]),
     'psvae_graph_rows_gated': (_c_int, [_c_int, _c_int, _p, _c_int, _p, _p, _p, _c_int, _p]),
     'psvae_gine_aggregate_bwd_workspace_bytes': (_c_size, [_c_int, _c_int, _c_int]),
+    'psvae_gine_aggregate_bwd_slabs': (_c_int, [_c_int, _c_int, _c_int]),
+    'psvae_gine_table_reduce': (_c_int, [_c_int, _c_int, _c_int, _p, _p, _c_int, _p]),
     'psvae_gine_aggregate_bwd': (_c_int, [_c_int, _c_int, _c_int, _p, _c_int, _p, _p, _c_int, _p, _p, _p, _p,
                                           _c_int, _p, _c_int, _p, _c_int, _p, _c_size, _p]),
     'psvae_gine_aggregate_bwd_noalloc': (_c_int, [_c_int, _c_int, _c_int, _p, _c_int, _p, _p, _c_int, _p, _p, _p, _p,
@@ -386,15 +388,27 @@ def gine_aggregate_fwd_bits(x, table, row_ptr, col, cls, out, mask):
 
 
 def gine_aggregate_bwd_bits(mask, C, g, t_row_ptr, t_col, t_cls, g_x, g_table, add=None, seg_add=None, node_graph=None,
-                            accumulate_table=False):
+                            accumulate_table=False, slabs=None):
     """psvae_gine_aggregate_bwd_bits: the backward from the mask bits (x and the table are not read);
-    seg_add [graphs, H] / node_graph [V]: a per-graph row added to every node of the graph."""
+    seg_add [graphs, H] / node_graph [V]: a per-graph row added to every node of the graph.
+    slabs [gine_bwd_slabs(V, H, C), C, H]: the table-gradient partials stay there and g_table is not
+    touched (gine_table_reduce sums the slabs of several calls at once)."""
     V, H = g.shape
     _count()
     with _Prof('gine_aggregate_bwd_kernel', aggregate_bytes(V, t_col.numel(), H, backward=True,
                                                             mask_bytes=mask.numel() * mask.element_size() // max(V, 1))):
         ops().gine_aggregate_bwd_bits(mask, C, g, t_row_ptr, t_col, t_cls, add, seg_add, node_graph, g_x, g_table,
-                                      accumulate_table)
+                                      accumulate_table, slabs)
+
+
+def gine_bwd_slabs(V, H, C):
+    return int(lib().psvae_gine_aggregate_bwd_slabs(int(V), int(H), int(C)))
+
+
+def gine_table_reduce(slabs, g_table, accumulate=False):
+    """g_table (+)= sum of the [C,H] slabs in slab order (psvae_gine_table_reduce)."""
+    _count()
+    ops().gine_table_reduce(slabs, g_table, accumulate)
 
 
 def graph_rows_gated(q, node_graph, gate_bits, out):

@@ -320,11 +320,15 @@ class _GineEncoder(Function):
         g_table = torch.empty_like(table)
         node_graph = pool.node_graph(V) if g_pool is not None else None
 
+        # the t layers share the bond table: with the mask bits their table-gradient partials are kept as slabs
+        # (one per workgroup and layer) and summed once behind the loop
+        slabs = torch.empty(t, hip.gine_bwd_slabs(V, H, C), C, H, **f32) if masks is not None and V > 0 else None
+
         def aggregate_bwd(i, x_prev, out, add, seg_add, first):
             if masks is not None:
                 hip.gine_aggregate_bwd_bits(masks[i], C, ga, csr.t_row_ptr, csr.t_col, csr.t_cls, out, g_table, add=add,
                                             seg_add=seg_add, node_graph=node_graph if seg_add is not None else None,
-                                            accumulate_table=not first)
+                                            accumulate_table=not first, slabs=None if slabs is None else slabs[i])
             else:
                 hip.gine_aggregate_bwd(x_prev, table, ga, csr.t_row_ptr, csr.t_col, csr.t_cls, out, g_table, add=add,
                                        accumulate_table=not first, seg_add=seg_add,
@@ -352,6 +356,10 @@ class _GineEncoder(Function):
                 aggregate_bwd(i, None if all_x is None else all_x[:, slot], gx[i - 1], add, seg_add, first)
             else:
                 aggregate_bwd(i, x0, g_x0, None, None, first)
+        if slabs is not None:
+            hip.gine_table_reduce(slabs.view(-1, C, H), g_table)
+        elif masks is not None:
+            g_table.zero_()                      # (no node: no slab was written)
         need = ctx.needs_input_grad
         gw2, gb2 = torch.empty_like(w2), torch.empty(H, **f32)
         gw1, gb1 = torch.empty_like(w1), torch.empty(H, **f32)

@@ -1303,3 +1303,43 @@ def test_pair_enumerate_against_the_masked_cells():
     for arr, key in zip(got[:5], ('src', 'dst', 'graph', 'm', 'k')):
         flat = np.concatenate([np.asarray(v).reshape(-1) for v in want[key]]) if want[key] else np.zeros(0)
         assert np.array_equal(arr.cpu().numpy(), flat.astype(np.int32)), key
+
+
+def test_gine_table_gradient_through_slabs():
+    """psvae_gine_aggregate_bwd_bits leaving its table-gradient partials as slabs and psvae_gine_table_reduce over
+    the slabs of two calls = the two calls' table gradients added; g_x is the same either way."""
+    from ps_vae_amd import hip, ops
+    d = dev()
+    V, H, C = 777, 300, 4
+    g0 = torch.Generator().manual_seed(9)
+    ei, attr, x, table = random_graph(V, H, C, seed=21)
+    csr = ops.Csr.from_edge_index(ei.to(d), attr.to(d), V)
+    x, table = x.to(d), table.to(d)
+    out = torch.empty(V, H, device=d)
+    words, wtype = hip.gine_mask_words(V, H, C)
+    mask = torch.zeros(words, dtype=wtype, device=d)
+    hip.gine_aggregate_fwd_bits(x, table, csr.row_ptr, csr.col, csr.cls, out, mask)
+    gs = [torch.randn(V, H, generator=g0).to(d) for _ in range(2)]
+    want_t = torch.zeros(C, H, device=d)
+    want_x = []
+    for i, gy in enumerate(gs):
+        gx = torch.empty(V, H, device=d)
+        hip.gine_aggregate_bwd_bits(mask, C, gy, csr.t_row_ptr, csr.t_col, csr.t_cls, gx, want_t, accumulate_table=i > 0)
+        want_x.append(gx)
+    n = hip.gine_bwd_slabs(V, H, C)
+    assert n >= 1
+    slabs = torch.full((2, n, C, H), float('nan'), device=d)
+    untouched = torch.full((C, H), 7.0, device=d)
+    for i, gy in enumerate(gs):
+        gx = torch.empty(V, H, device=d)
+        hip.gine_aggregate_bwd_bits(mask, C, gy, csr.t_row_ptr, csr.t_col, csr.t_cls, gx, untouched, slabs=slabs[i])
+        assert torch.equal(gx, want_x[i])
+    assert bool((untouched == 7.0).all())
+    got_t = torch.empty(C, H, device=d)
+    hip.gine_table_reduce(slabs.view(-1, C, H), got_t)
+    close(got_t, want_t, what='table gradient through slabs')
+    again = torch.empty(C, H, device=d)
+    hip.gine_table_reduce(slabs.view(-1, C, H), again)
+    assert torch.equal(again, got_t)
+    hip.gine_table_reduce(slabs.view(-1, C, H), again, accumulate=True)
+    close(again, 2 * want_t, what='accumulated')
