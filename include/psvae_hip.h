@@ -476,7 +476,7 @@ int psvae_piece_draw(int B, int V, const float *logits, int64_t ld_logits, float
  * different fragments, in row-major order.  _count writes the number per molecule; after
  * ptr = exclusive scan of counts, _fill writes for candidate ptr[b] + j the global atom ids src / dst, the
  * molecule id graph and the molecule-local ids m / k.  max_atoms: at least the largest molecule (it sizes the
- * LDS stage; at most 15 360).
+ * LDS stage; at most 15 360) - a molecule with more atoms is treated as its first max_atoms atoms, by both calls.
  * ---------------------------------------------------------------------------------- */
 int psvae_pair_enumerate_count(int B, int max_atoms, const int32_t *node_off, const int32_t *frag, int32_t *counts,
                                void *stream);

@@ -135,7 +135,7 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int *scratch /* [ENUM
 }
 
 template <bool FILL>
-__global__ __launch_bounds__(ENUM_THREADS) void pair_enumerate_kernel(int B, const int32_t *__restrict__ node_off,
+__global__ __launch_bounds__(ENUM_THREADS) void pair_enumerate_kernel(int B, int max_atoms, const int32_t *__restrict__ node_off,
                                                                       const int32_t *__restrict__ frag,
                                                                       int32_t *__restrict__ counts,
                                                                       const int32_t *__restrict__ ptr, int32_t *__restrict__ src,
@@ -144,7 +144,8 @@ __global__ __launch_bounds__(ENUM_THREADS) void pair_enumerate_kernel(int B, con
     extern __shared__ int32_t s_frag[];          // [n]
     __shared__ int scratch[ENUM_THREADS / 64 + 1];
     const int b = blockIdx.x;
-    const int base = node_off[b], n = node_off[b + 1] - base;
+    const int base = node_off[b];
+    const int n = min(node_off[b + 1] - base, max_atoms);   // (the LDS stage holds max_atoms ids: a larger molecule is cut there)
     for (int i = threadIdx.x; i < n; i += ENUM_THREADS) s_frag[i] = frag[base + i];
     __syncthreads();
     int running = 0;                              // candidates of the rows before this round of ENUM_THREADS rows
@@ -182,7 +183,7 @@ extern "C" int psvae_pair_enumerate_count(int B, int max_atoms, const int32_t *n
     if (B == 0) return PSVAE_OK;
     PSVAE_REQUIRE(node_off && counts && (frag || max_atoms == 0), PSVAE_EINVAL, "%s: null pointer", fn);
     hipLaunchKernelGGL(pair_enumerate_kernel<false>, dim3(B), dim3(ENUM_THREADS), (size_t)(max_atoms > 0 ? max_atoms : 1) * sizeof(int32_t),
-                       (hipStream_t)stream, B, node_off, frag, counts, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+                       (hipStream_t)stream, B, max_atoms, node_off, frag, counts, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     PSVAE_CHECK_LAUNCH(fn);
     return PSVAE_OK;
 }
@@ -197,7 +198,7 @@ extern "C" int psvae_pair_enumerate_fill(int B, int max_atoms, const int32_t *no
     PSVAE_REQUIRE(node_off && ptr && (frag || max_atoms == 0), PSVAE_EINVAL, "%s: null pointer", fn);
     PSVAE_REQUIRE(src && dst && graph && m && k, PSVAE_EINVAL, "%s: null output", fn);
     hipLaunchKernelGGL(pair_enumerate_kernel<true>, dim3(B), dim3(ENUM_THREADS), (size_t)(max_atoms > 0 ? max_atoms : 1) * sizeof(int32_t),
-                       (hipStream_t)stream, B, node_off, frag, nullptr, ptr, src, dst, graph, m, k);
+                       (hipStream_t)stream, B, max_atoms, node_off, frag, nullptr, ptr, src, dst, graph, m, k);
     PSVAE_CHECK_LAUNCH(fn);
     return PSVAE_OK;
 }
