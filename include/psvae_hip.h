@@ -247,6 +247,20 @@ int psvae_gine_aggregate_bwd_noalloc(int V, int H, int C, const float *x, int ld
                                      int accumulate_table, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * Hidden layer + class layer of the link predictor over all candidate pairs of generated molecules
+ * (src/modules/vae_piece_decoder.py:224-238: the MLP's Linear + ReLU followed by the class Linear), the
+ * [M,N] hidden rows never written:
+ *   partials[m][t][c] = sum over the columns n of column tile t of relu(A[m] . W[n] + bias[n]) * cls_w[c][n]
+ * for the 4 classes c; logits[m][c] = sum_t partials[m][t][c] + the class bias (left to the caller).
+ * A [M,K] rows lda apart, W [N,K] rows ldw apart, bias [N] or null, cls_w [4][N] contiguous (rows of unused
+ * classes zero), partials [M][tiles][4] with tiles = psvae_gemm_f32_relu_classes_tiles(N) (0: this N is not
+ * covered - the column tiles must be 129..192 columns wide, e.g. N in 132..192 or 260..384).
+ * ---------------------------------------------------------------------------------- */
+int psvae_gemm_f32_relu_classes_tiles(int N);
+int psvae_gemm_f32_relu_classes(int M, int N, int K, const float *A, int64_t lda, const float *W, int64_t ldw,
+                                const float *bias, const float *cls_w, float *partials, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * f32 matrix product on the matrix cores (v_mfma_f32_32x32x2_f32: exact f32 FMA chains):
  *     C[m][n] (+)= act( sum_k A(m,k) * B(k,n) + bias[n] )
  * A(m,k) = A[m*sa_m + k*sa_k], B(k,n) = B[k*sb_k + n*sb_n]: any of the Linear products

@@ -330,6 +330,7 @@ static int gemm_impl(int M, int N, int K, const float *A, const float *amask, in
     g.C = C, g.ldc = ldc, g.bias = bias, g.rowsum = rowsum, g.cmask = cmask, g.act = act;
     g.accumulate = accumulate, g.split_k = split_k, g.k_chunk = k_chunk, g.ws = (float *)workspace, g.tail_begin = K;
     g.relu_bits = relu_bits, g.gate_bits = gate_bits, g.bits_ng = psvae_cdiv(N, 32);
+    g.cls_w = nullptr, g.cls_out = nullptr;
     if (relu_bits || gate_bits) {
         PSVAE_REQUIRE((tile64 || panel) && split_k == 1 && g.c_vec != 0 && rowsum == nullptr, PSVAE_EINVAL,
                       "psvae_gemm_f32_bits: needs the 16-byte-aligned kernels, no K split and no rowsum "
@@ -387,6 +388,42 @@ extern "C" int psvae_gemm_f32(int M, int N, int K, const float *A, const float *
                               int split_k, void *workspace, size_t workspace_bytes, void *stream) {
     return gemm_impl(M, N, K, A, amask, sa_m, sa_k, B, sb_k, sb_n, C, ldc, bias, rowsum, cmask, act, accumulate, split_k,
                      workspace, workspace_bytes, stream, nullptr, nullptr);
+}
+
+// ---- X W^T + b, ReLU, and a 4-class layer on top, the [M,N] intermediate never written
+extern "C" int psvae_gemm_f32_relu_classes_tiles(int N) {
+    if (N <= 0 || N % 4 != 0) return 0;
+    int nc, bn, tn;
+    panel_shape(N, nc, bn, tn);
+    return (tn == 5 || tn == 6) ? nc : 0;
+}
+
+extern "C" int psvae_gemm_f32_relu_classes(int M, int N, int K, const float *A, int64_t lda, const float *W, int64_t ldw,
+                                           const float *bias, const float *cls_w, float *partials, void *stream) {
+    const char *fn = "psvae_gemm_f32_relu_classes";
+    PSVAE_REQUIRE(M >= 0 && N > 0 && K > 0, PSVAE_EINVAL, "%s: bad sizes M=%d N=%d K=%d", fn, M, N, K);
+    if (M == 0) return PSVAE_OK;
+    const int tiles = psvae_gemm_f32_relu_classes_tiles(N);
+    PSVAE_REQUIRE(tiles > 0, PSVAE_EINVAL, "%s: N=%d is not covered (column tiles of 129..192 columns, N a multiple of 4)", fn, N);
+    PSVAE_REQUIRE(A && W && cls_w && partials && K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0 && lda >= K && ldw >= K &&
+                      psvae_aligned16(A) && psvae_aligned16(W) && psvae_aligned16(cls_w) && psvae_aligned16(partials) &&
+                      (bias == nullptr || psvae_aligned16(bias)), PSVAE_EINVAL,
+                  "%s: operands must be 16-byte aligned with row strides and K multiples of 4", fn);
+    int nc, bn, tn;
+    panel_shape(N, nc, bn, tn);
+    GemmArgs g;
+    g.M = M, g.N = N, g.K = K, g.n_ext = N, g.ws_ld = (N + 3) / 4 * 4;
+    g.A = A, g.amask = nullptr, g.sa_m = lda, g.sa_k = 1, g.B = W, g.sb_k = 1, g.sb_n = ldw;
+    g.C = nullptr, g.ldc = N, g.bias = bias, g.rowsum = nullptr, g.cmask = nullptr, g.act = PSVAE_ACT_RELU, g.accumulate = 0;
+    g.split_k = 1, g.k_chunk = psvae_cdiv(K, PSVAE_PANEL_BK) * PSVAE_PANEL_BK, g.ws = nullptr, g.c_vec = 2, g.tail_begin = K;
+    g.nt_m = psvae_cdiv(M, 128), g.nt_n = nc, g.bn = bn, g.wn = 1;
+    g.relu_bits = nullptr, g.gate_bits = nullptr, g.bits_ng = 0;
+    g.cls_w = cls_w, g.cls_out = partials;
+    const long long blocks = (long long)psvae_cdiv((long long)g.nt_m, 8) * 8 * g.nt_n;
+    PSVAE_REQUIRE(blocks < (1ll << 31), PSVAE_ETOOLARGE, "%s: grid too large", fn);
+    launch_panel_classes(g, tn, dim3((unsigned)blocks), (hipStream_t)stream);
+    PSVAE_CHECK_LAUNCH(fn);
+    return PSVAE_OK;
 }
 
 extern "C" size_t psvae_gemm_f32_bits_words(int M, int N) {

@@ -48,6 +48,10 @@ struct GemmArgs {
     unsigned long long *relu_bits;
     const unsigned long long *gate_bits;
     int bits_ng;          // 32-column groups per row of C: ceil(N / 32)
+    // Class layer in the epilogue (psvae_gemm_f32_relu_classes): C is not written; every column tile adds its
+    // part of relu(result + bias) . cls_w[c] for the 4 classes to cls_out[row][tile_n][c].
+    const float *cls_w;   // [4][N]
+    float *cls_out;       // [M][nt_n][4]
 };
 
 __device__ __forceinline__ void epilogue_store(const GemmArgs &g, int row, int col, float v) {
@@ -90,6 +94,8 @@ __device__ __forceinline__ bool tile_of_block(const GemmArgs &g, int &tile_m, in
 // variants compile in parallel).
 template <int TN, int BK>
 void launch_panel(const GemmArgs &g, bool a_kc, bool b_kc, dim3 grid, hipStream_t s);
+// the forward form X W^T with the class layer in the epilogue, TN = 5 or 6 (panel_cls_inst.hip)
+void launch_panel_classes(const GemmArgs &g, int tn, dim3 grid, hipStream_t s);
 
 // ---- 64 x 64 tiles for small products (tile64_inst.hip)
 #ifndef PSVAE_TILE64_BK

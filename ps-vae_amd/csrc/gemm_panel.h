@@ -88,7 +88,7 @@ struct TileLoader {
 // WN = 1: the 4 waves stack along M (128-row panel, 32*TN columns).  WN = 2: a 2 x 2 wave grid
 // (64 rows x 64*TN columns), for products whose M fits 64-row panels with less padding and, with
 // TN = 1 (64 x 64 tiles, tile64_inst.hip), for products too small to fill the chip with panels.
-template <int TN, int BK, bool A_KC, bool B_KC, bool MASK, bool ONES, int WN = 1>
+template <int TN, int BK, bool A_KC, bool B_KC, bool MASK, bool ONES, int WN = 1, bool CLS = false>
 __global__ __launch_bounds__(THREADS, (MASK || WN > 1 || TN > 5) ? 2 : PSVAE_PANEL_OCC) void gemm_panel_kernel(GemmArgs g) {
     constexpr int WM = 4 / WN, BM = 32 * WM, BN = 32 * TN * WN;
     using LA = TileLoader<BM, BK, A_KC>;
@@ -228,6 +228,61 @@ __global__ __launch_bounds__(THREADS, (MASK || WN > 1 || TN > 5) ? 2 : PSVAE_PAN
     // 128-B row segments.  Instead every wave transposes one tile at a time through its own
     // 32 x 36 LDS patch and writes float4 per lane: 4 store instructions of 8 rows x 128 B.
     const int col_lim = min(g.n_ext, n0 + g.bn);
+    if constexpr (CLS) {
+        // The result tile is not written: relu(acc + bias) is multiplied into the 4-class layer on the spot.
+        // After a tile's transposition through the patch lane (prow, pc4) holds columns pc4 .. pc4 + 3 of rows
+        // prow + 8 i; it adds their products with the four class rows to 16 running sums (row group x class),
+        // which are then summed over the 8 lanes of a row (fixed order) and written as one float4 per row.
+        static_assert(WN == 1, "class epilogue: 4 x 1 wave grid");
+        float *patch = smem + wave * 32 * EPI_STRIDE;
+        const int prow = lane >> 3, pc4 = (lane & 7) * 4;
+        float part[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) part[i][c] = 0.f;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int cbase = n0 + j * 32;
+            if (cbase >= col_lim) continue;   // wave-uniform
+            const int col = cbase + pc4;
+            const bool in = col < g.N;        // (N % 4 == 0: a lane's four columns are inside together)
+            float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f), w4[4];
+            if (in && g.bias != nullptr) b4 = *reinterpret_cast<const float4 *>(g.bias + col);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                w4[c] = in ? *reinterpret_cast<const float4 *>(g.cls_w + (long long)c * g.N + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                patch[((r & 3) + 8 * (r >> 2) + 4 * lhi) * EPI_STRIDE + l31] = acc[j][r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float4 v = *reinterpret_cast<const float4 *>(patch + (prow + 8 * i) * EPI_STRIDE + pc4);
+                v.x = fmaxf(v.x + b4.x, 0.f), v.y = fmaxf(v.y + b4.y, 0.f), v.z = fmaxf(v.z + b4.z, 0.f), v.w = fmaxf(v.w + b4.w, 0.f);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    part[i][c] += (v.x * w4[c].x + v.y * w4[c].y) + (v.z * w4[c].z + v.w * w4[c].w);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // patch is rewritten by the next tile
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float x = part[i][c];
+                x += __shfl_xor(x, 1);
+                x += __shfl_xor(x, 2);
+                x += __shfl_xor(x, 4);
+                part[i][c] = x;
+            }
+            const int row = m0 + wave_m * 32 + prow + 8 * i;
+            if ((lane & 7) == 0 && row < g.M)
+                *reinterpret_cast<float4 *>(g.cls_out + ((long long)row * g.nt_n + tile_n) * 4) =
+                    make_float4(part[i][0], part[i][1], part[i][2], part[i][3]);
+        }
+        return;
+    }
     const bool split = g.split_k > 1;
     float *out = split ? g.ws + (long long)z * g.M * g.ws_ld : g.C;
     const long long ld = split ? g.ws_ld : g.ldc;
@@ -443,6 +498,12 @@ void launch_panel(const GemmArgs &g, bool a_kc, bool b_kc, dim3 grid, hipStream_
         else PSVAE_PANEL(false, false, false, false);
     }
 #undef PSVAE_PANEL
+}
+
+// (instantiated in panel_cls_inst.hip only)
+template <int TN>
+void launch_panel_classes_tn(const GemmArgs &g, dim3 grid, hipStream_t s) {
+    hipLaunchKernelGGL((gemm_panel_kernel<TN, PSVAE_PANEL_BK, true, true, false, false, 1, true>), grid, dim3(THREADS), 0, s, g);
 }
 
 }  // namespace psvae_gemm

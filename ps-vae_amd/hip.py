@@ -83,6 +83,8 @@ _SIGNATURES = {
     'psvae_token_ce_workspace_bytes': (_c_size, [_c_int]),
     'psvae_token_ce_fwd': (_c_int, [_c_int, _c_int, _p, _c_i64, _p, _c_int, _p, _c_i64, _p, _p, _p, _c_size, _p]),
     'psvae_link_infer': (_c_int, [_c_int, _c_int, _p, _c_f32, _c_int, _p, _p, _p, _p]),
+    'psvae_gemm_f32_relu_classes_tiles': (_c_int, [_c_int]),
+    'psvae_gemm_f32_relu_classes': (_c_int, [_c_int, _c_int, _c_int, _p, _c_i64, _p, _c_i64, _p, _p, _p, _p]),
     'psvae_pair_enumerate_count': (_c_int, [_c_int, _c_int, _p, _p, _p, _p]),
     'psvae_pair_enumerate_fill': (_c_int, [_c_int, _c_int, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     'psvae_piece_draw': (_c_int, [_c_int, _c_int, _p, _c_i64, _c_f32, _p, _c_i64, _c_int, _c_int, _c_int, _p, _c_int, _c_int,
@@ -583,6 +585,23 @@ def token_ce_fwd(logits, gold, ignore_index, n_classes, dlogits, loss, counts):
     rows are wide: columns from n_classes on are zeroed), loss f32[2], counts i32[2]."""
     _count()
     ops().token_ce_fwd(logits, gold, int(ignore_index), int(n_classes), dlogits, loss, counts)
+
+
+def relu_classes_tiles(N):
+    return int(lib().psvae_gemm_f32_relu_classes_tiles(int(N)))
+
+
+def gemm_relu_classes(x, weight, bias, cls_w4, partials):
+    """psvae_gemm_f32_relu_classes: partials[m][t][c] = sum over column tile t of relu(x W^T + b) * cls_w4[c]."""
+    M, K = x.shape
+    N = weight.shape[0]
+    _count()
+    px, ldx = _rows(x)
+    pw, ldw = _rows(weight)
+    with _Prof('gemm_f32_kernel', 2.0 * M * N * (K + 4), (M, N, K, 'k', 'k', False, False)):
+        _check(lib().psvae_gemm_f32_relu_classes(M, N, K, px, ldx, pw, ldw, ptr(bias, torch.float32) if bias is not None else None,
+                                                 ptr(cls_w4, torch.float32), ptr(partials, torch.float32), _stream()),
+               'psvae_gemm_f32_relu_classes')
 
 
 def pair_enumerate(node_off, frag, max_atoms):

@@ -136,8 +136,16 @@ class VAEPieceDecoder(nn.Module):
             huv = ops.linear(node_embedding, w_nodes)                  # [V, 2F]
             hz = ops.linear(z_vecs, w_z, first.bias)                   # [B, F]
             hid = ops.pair_combine(huv, hz, pairs, relu=True)
-            hid = run_sequential(seq[2:-1], hid)
             weight, bias = ops.affine_merge(last.weight, last.bias, seq[-1].weight, seq[-1].bias)
+            inner = seq[2:-1]
+            if (golden is None and not torch.is_grad_enabled() and len(inner) == 2 and isinstance(inner[0], nn.Linear)
+                    and isinstance(inner[1], nn.ReLU)):
+                # generation: hidden Linear + ReLU + class layer as one product whose [P, F] result is never
+                # written (the class layer runs in the product's epilogue)
+                logits = ops.linear_relu_classes(hid, inner[0].weight, inner[0].bias, weight, bias)
+                if logits is not None:
+                    return logits, None, None
+            hid = run_sequential(inner, hid)
             if golden is None:
                 return ops.linear(hid, weight, bias), None, None
             loss, logits, n_ok = ops.link_ce(hid, weight, bias, golden, getattr(pairs, 'live', None))

@@ -935,3 +935,21 @@ def token_ce(logits, gold, ignore_index, n_classes=None):
     #rows whose argmax is the label]."""
     width = logits.shape[-1]
     return _TokenCe.apply(logits.reshape(-1, width), gold.reshape(-1), ignore_index, width if n_classes is None else n_classes)
+
+
+def linear_relu_classes(x, weight, bias, cls_weight, cls_bias):
+    """relu(x W^T + b) C^T + c for a class layer C of at most 4 rows, without gradients and without the
+    [M, N] intermediate in memory (psvae_gemm_f32_relu_classes: the class layer is applied per column tile in
+    the product's epilogue, the tiles' parts are added here).  None when the shape is not covered."""
+    M, K = x.shape
+    N, C = weight.shape[0], cls_weight.shape[0]
+    tiles = hip.relu_classes_tiles(N)
+    if tiles == 0 or C > 4 or K % 4 or M == 0 or x.stride(1) != 1 or x.stride(0) % 4 or not weight.is_contiguous():
+        return None
+    w4 = cls_weight.detach()
+    if C < 4:
+        w4 = torch.cat([w4, w4.new_zeros(4 - C, N)], dim=0)
+    partials = torch.empty(M, tiles, 4, dtype=torch.float32, device=x.device)
+    hip.gemm_relu_classes(x, weight.detach(), None if bias is None else bias.detach(), w4.contiguous(), partials)
+    logits = partials.sum(dim=1)[:, :C]
+    return logits + cls_bias.detach() if cls_bias is not None else logits

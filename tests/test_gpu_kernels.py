@@ -1343,3 +1343,22 @@ def test_gine_table_gradient_through_slabs():
     assert torch.equal(again, got_t)
     hip.gine_table_reduce(slabs.view(-1, C, H), again, accumulate=True)
     close(again, 2 * want_t, what='accumulated')
+
+
+@pytest.mark.parametrize('M,N,K,C', [(1, 328, 328, 4), (1000, 328, 328, 4), (130, 160, 64, 3), (4099, 384, 300, 4), (257, 132, 8, 1)])
+def test_gemm_relu_classes(M, N, K, C):
+    """psvae_gemm_f32_relu_classes (hidden Linear + ReLU + class layer, the hidden rows never written) against
+    the same arithmetic in float64."""
+    from ps_vae_amd import hip, ops
+    d = dev()
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g)
+    w, b = torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g)
+    cw, cb = torch.randn(C, N, generator=g) / N ** 0.5, torch.randn(C, generator=g)
+    want = torch.relu(x.double() @ w.double().T + b.double()) @ cw.double().T + cb.double()
+    assert hip.relu_classes_tiles(N) in (1, 2) and hip.relu_classes_tiles(100) == 0 and hip.relu_classes_tiles(600) == 0
+    got = ops.linear_relu_classes(x.to(d), w.to(d), b.to(d), cw.to(d), cb.to(d))
+    close(got, want, what='logits')
+    nobias = ops.linear_relu_classes(x.to(d), w.to(d), None, cw.to(d), None)
+    close(nobias, torch.relu(x.double() @ w.double().T) @ cw.double().T, what='logits without biases')
+    assert ops.linear_relu_classes(x.to(d), w[:100].contiguous().to(d), b[:100].to(d), cw[:, :100].contiguous().to(d), cb.to(d)) is None
