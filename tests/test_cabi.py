@@ -134,6 +134,28 @@ def test_rejected_arguments_return_codes_without_touching_the_gpu():
 
     # link loss / inference helpers
     assert L.psvae_link_infer(0, 4, null, 0.5, 0, null, null, null, null) == 0
+
+    # generation: sampling step, candidate pairs, hidden + class layer in one product
+    draw = L.psvae_piece_draw
+    assert draw(0, 302, null, 302, 1.0, null, 1, 300, 301, 1, null, 38, 50, null, null, null, null, 1, null, null) == 0
+    assert draw(4, 302, P, 300, 1.0, P, 1, 300, 301, 1, P, 38, 50, P, P, P, P, 1, P, null) == EINVAL      # rows shorter than V
+    assert draw(4, 302, P, 302, 0.0, P, 1, 300, 301, 1, P, 38, 50, P, P, P, P, 1, P, null) == EINVAL      # temperature
+    assert draw(4, 302, P, 302, 1.0, P, 1, 302, 301, 1, P, 38, 50, P, P, P, P, 1, P, null) == EINVAL      # pad outside the vocabulary
+    assert draw(4, 302, P, 302, 1.0, null, 1, 300, 301, 1, P, 38, 50, P, P, P, P, 1, P, null) == EINVAL
+    assert L.psvae_pair_enumerate_count(0, 0, null, null, null, null) == 0
+    assert L.psvae_pair_enumerate_count(3, 40, null, P, P, null) == EINVAL
+    assert L.psvae_pair_enumerate_count(3, 20000, P, P, P, null) == ETOOLARGE
+    assert L.psvae_pair_enumerate_fill(3, 40, P, P, P, P, P, P, P, null, null) == EINVAL
+    tiles = L.psvae_gemm_f32_relu_classes_tiles
+    assert tiles(328) == 2 and tiles(160) == 1 and tiles(300) == 2 and tiles(100) == 0 and tiles(600) == 0 and tiles(330) == 0
+    rc = L.psvae_gemm_f32_relu_classes
+    assert rc(0, 328, 328, null, 328, null, 328, null, null, null, null) == 0
+    assert rc(8, 100, 328, P, 328, P, 328, P, P, P, null) == EINVAL          # width not covered
+    assert rc(8, 328, 326, P, 328, P, 328, P, P, P, null) == EINVAL          # K not a multiple of 4
+    assert rc(8, 328, 328, P, 328, P, 328, P, null, P, null) == EINVAL       # no class rows
+    assert L.psvae_gine_aggregate_bwd_slabs(0, 300, 4) == 0 and 1 <= L.psvae_gine_aggregate_bwd_slabs(95000, 300, 4) <= 1024
+    assert L.psvae_gine_table_reduce(0, 4, 300, null, null, 0, null) == EINVAL                   # no output
+    assert L.psvae_gine_table_reduce(3, 4, 300, null, P, 0, null) == EINVAL                      # slabs missing
     assert ETOOLARGE == -2
 
 
