@@ -335,12 +335,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # a full collection over the interpreter's ~1e6 module objects costs ~100 ms; take it after the first
+    # warm-up step and freeze the survivors, so that it can land neither inside the timed region nor right
+    # in front of it (the GPU would sit idle for that long and start the timed steps from its idle clocks)
+    for w in range(args.warmup):
         step()
-    # a full collection over the interpreter's ~1e6 module objects costs ~100 ms; take it now
-    # and freeze the survivors so that it cannot land inside the timed region
-    gc.collect()
-    gc.freeze()
+        if w == 0:
+            gc.collect()
+            gc.freeze()
+    if args.warmup == 0:
+        gc.collect()
+        gc.freeze()
     # Kernel events are recorded on a few of the timed steps only (they cost ~0.6 ms of host
     # time per step).  Steps 4, 12, 20, ... run with everything on ONE stream and fill `prof`:
     # their brackets time each kernel alone.  Steps 8, 24, ... keep the two streams and fill
