@@ -92,12 +92,13 @@ def freq_cnt(mol):
     return freqs, mol
 
 
-def graph_bpe(fname, vocab_len, vocab_path=None, smiles=None, log=None):
+def graph_bpe(fname, vocab_len, vocab_path=None, cpus=1, smiles=None, log=None):
     """Mine `vocab_len` pieces from the SMILES file `fname` (or the list `smiles`): the 10 atoms, then
     the most frequent neighbouring-piece merge, one per round (mol_bpe.py:108-153).  Returns
     (pieces sorted by atom count, details {piece: [atom count, frequency]}) and writes the
     `smiles\\tatoms\\tfrequency` text file when vocab_path is given.  Molecules with a '+' in their
-    SMILES are left out, as the reference leaves them out; unreadable ones are skipped."""
+    SMILES are left out, as the reference leaves them out; unreadable ones are skipped.  `cpus` is the
+    reference's worker count: accepted and not used, the rounds run in this process."""
     if smiles is None:
         with open(fname, 'r') as fin:
             smiles = [line.strip() for line in fin if line.strip()]
@@ -209,7 +210,7 @@ def parse(argv=None):
 def main(argv=None):
     from ..utils.tokenizer import Tokenizer
     args = parse(argv)
-    graph_bpe(args.data, vocab_len=args.vocab_size, vocab_path=args.output, log=print)
+    graph_bpe(args.data, vocab_len=args.vocab_size, vocab_path=args.output, cpus=args.workers, log=print)
     tokenizer = Tokenizer(args.output)
     print(f'Example: {args.smiles}')
     print(tokenizer.tokenize(args.smiles))
