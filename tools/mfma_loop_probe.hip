@@ -162,6 +162,99 @@ __global__ __launch_bounds__(256, 3) void probe(float *out, const float4 *src, i
     out[blockIdx.x * 256 + tid] = s;
 }
 
+
+// Producer / consumer split: a fifth wave does all global loads and staging stores of the workgroup (36 loads and
+// 144 ds_write_b32 per k-tile), the four others only read operands from LDS and multiply; two LDS stages, one
+// barrier per k-tile.  WGS workgroups per CU are resident (register budget permitting).
+template <int WGS>
+__global__ __launch_bounds__(320, WGS) void probe_split(float *out, const float4 *src, int tiles, long long src_quads) {
+    __shared__ float As[2][BK * A_STRIDE];
+    __shared__ float Bs[2][BK * B_STRIDE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+    for (int i = tid; i < 2 * BK * A_STRIDE; i += 320) (&As[0][0])[i] = 0.001f * (i % 97);
+    for (int i = tid; i < 2 * BK * B_STRIDE; i += 320) (&Bs[0][0])[i] = 0.002f * (i % 89);
+    __syncthreads();
+    f32x16 acc[TN];
+    for (int j = 0; j < TN; ++j) for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    float s = 0.f;
+    if (wave == 4) {
+        long long gq = ((long long)blockIdx.x * 64 + lane) % src_quads;
+        float4 stage[36];
+        for (int t = 0; t < tiles; ++t) {
+#pragma unroll
+            for (int i = 0; i < 36; ++i) {
+                if (i < 16) {
+                    stage[i] = src[gq];
+                    gq += 64 * 768;
+                    if (gq >= src_quads) gq -= src_quads;
+                } else {
+                    stage[i] = src[((t % 10) * 20 + i - 16) * 64 + lane];
+                }
+            }
+            float *a = As[(t + 1) & 1], *b = Bs[(t + 1) & 1];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int item = lane + 64 * i;
+                float *d = a + (4 * (item % 8)) * A_STRIDE + item / 8;
+                d[0] = stage[i].x, d[A_STRIDE] = stage[i].y, d[2 * A_STRIDE] = stage[i].z, d[3 * A_STRIDE] = stage[i].w;
+            }
+#pragma unroll
+            for (int i = 0; i < 20; ++i) {
+                const int item = lane + 64 * i;
+                float *d = b + (4 * (item % 8)) * B_STRIDE + item / 8;
+                d[0] = stage[16 + i].x, d[B_STRIDE] = stage[16 + i].y, d[2 * B_STRIDE] = stage[16 + i].z, d[3 * B_STRIDE] = stage[16 + i].w;
+            }
+            __syncthreads();
+        }
+        s = stage[0].x;
+    } else {
+        for (int t = 0; t < tiles; ++t) {
+            const float *ar = As[t & 1] + lhi * A_STRIDE + wave * 32 + l31, *br = Bs[t & 1] + lhi * B_STRIDE + l31;
+            float a_cur = ar[0], b_cur[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b_cur[j] = br[j * 32];
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 2) {
+                float a_nxt = a_cur, b_nxt[TN];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b_nxt[j] = b_cur[j];
+                if (kk + 2 < BK) {
+                    a_nxt = ar[(kk + 2) * A_STRIDE];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) b_nxt[j] = br[(kk + 2) * B_STRIDE + j * 32];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur[j], acc[j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                a_cur = a_nxt;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b_cur[j] = b_nxt[j];
+            }
+            __syncthreads();
+        }
+        for (int j = 0; j < TN; ++j) for (int r = 0; r < 16; ++r) s += acc[j][r];
+    }
+    out[blockIdx.x * 320 + tid] = s;
+}
+
+template <int WGS>
+void run_split(float *out, const float4 *src, long long quads, int blocks) {
+    const int tiles = 200;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e9f;
+    for (int rep = 0; rep < 4; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(probe_split<WGS>, dim3(blocks), dim3(320), 0, 0, out, src, tiles, quads);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    const double flop = (double)blocks * 4 * tiles * 16 * TN * 4096.0;
+    printf("producer/consumer, %d workgroups per CU asked, blocks %4d: %.3f ms  %.1f TFLOP/s (%.2f of 157.3)\n", WGS, blocks, best,
+           flop / best / 1e9, flop / best / 1e9 / 157.3);
+}
+
 template <int MODE>
 void run(float *out, const float4 *src, long long quads, int blocks) {
     const int tiles = 200;
@@ -179,7 +272,7 @@ void run(float *out, const float4 *src, long long quads, int blocks) {
 }
 
 int main() {
-    float *out; hipMalloc(&out, 4096 * 256 * 4);
+    float *out; hipMalloc(&out, 4096 * 320 * 4);
     const long long quads = 64ll << 20;   // 1 GiB of source rows
     float4 *src; hipMalloc(&src, quads * 16); hipMemset(src, 0, quads * 16);
     for (int blocks : {768, 1536}) {
@@ -200,6 +293,8 @@ int main() {
         run<64 + 2 + 4 + 8>(out, src, quads, blocks);
         run<256 + 11>(out, src, quads, blocks);
         run<256 + 15>(out, src, quads, blocks);
+        run_split<2>(out, src, quads, blocks);
+        run_split<3>(out, src, quads, blocks);
     }
     return 0;
 }
