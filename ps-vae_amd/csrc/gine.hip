@@ -257,7 +257,11 @@ Shape shape_for(int V, int H, int max_blocks) {
     s.cols = H / 4;
     s.slots = s.cols >= 256 ? 1 : psvae_cdiv(256, s.cols);
     s.threads = psvae_cdiv(s.cols * s.slots, 64) * 64;
-    s.nodes_per_block = 8 * s.slots;
+    // eight rows per thread slot, fewer where that would leave most CUs without a workgroup (a batch of 32
+    // molecules has ~750 nodes: 24 workgroups of 8 sequential row trips against 188 of one)
+    int rows = 8;
+    while (rows > 1 && (long long)psvae_cdiv(V, rows * s.slots) < 512) rows >>= 1;
+    s.nodes_per_block = rows * s.slots;
     s.blocks = psvae_cdiv(V, s.nodes_per_block);
     if (max_blocks > 0 && s.blocks > max_blocks) {
         s.nodes_per_block = psvae_cdiv(psvae_cdiv(V, max_blocks), s.slots) * s.slots;

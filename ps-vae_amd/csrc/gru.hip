@@ -7,8 +7,10 @@
 //     gh = h W_hh^T + b_hh           (16 x 3H, v_mfma_f32_16x16x4_f32: exact f32)
 //     r = s(gi_r + gh_r), z = s(gi_z + gh_z), n = tanh(gi_n + r gh_n), h' = (1 - z) n + z h
 // (PyTorch gate order r, z, n; gi = x W_ih^T + b_ih comes from one large product beforehand).
-// Hidden units are cut into blocks of 16; wave w owns blocks w, w + 4, ... and, for each, the
-// three gate tiles of those units.  The product is taken transposed (gh^T = W_hh h^T: A = W_hh,
+// Hidden units are cut into blocks of 16; wave w of the NW waves owns blocks w, w + NW, ... and, for
+// each, the three gate tiles of those units (NW = 16 for the model's 200 units: one block per wave, a
+// step's ~1900 MFMAs spread over 13 waves instead of 4 - the recurrence is a serial chain of steps, so
+// the time of one step is what counts: 15 -> 5 us).  The product is taken transposed (gh^T = W_hh h^T: A = W_hh,
 // B = h^T), so that in the accumulator layout a lane is a batch row and its four registers are
 // four CONSECUTIVE hidden units: the gate arithmetic runs on the accumulators where they are and
 // every global access of the step (gi, gates, hidden states) is 16 bytes per lane.  The new
@@ -29,7 +31,7 @@ namespace {
 
 constexpr int GRU_ROWS = 16;        // batch rows per workgroup
 constexpr int GRU_LD = 20;          // LDS row stride of the k-major operand images
-constexpr int GRU_THREADS = 256;
+constexpr int GRU_WAVES_WIDE = 16;  // waves per workgroup when the hidden width has more than four blocks of 16 units
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
@@ -44,8 +46,9 @@ struct GruFwdArgs {
     float *ghn;           // [T,B,H]  W_hn h + b_hn, needed by the backward, or null
 };
 
-template <int JB>
-__global__ __launch_bounds__(GRU_THREADS, 1) void gru_seq_fwd_kernel(GruFwdArgs a) {
+template <int JB, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void gru_seq_fwd_kernel(GruFwdArgs a) {
+    constexpr int GRU_THREADS = 64 * NW;
     extern __shared__ __align__(16) float lds[];
     const int H = a.H, B = a.B, H3 = 3 * a.H;
     const int KP = (H + 15) & ~15, nblk = KP >> 4;
@@ -73,7 +76,7 @@ __global__ __launch_bounds__(GRU_THREADS, 1) void gru_seq_fwd_kernel(GruFwdArgs 
     const float *wrow[JB][3];
 #pragma unroll
     for (int q = 0; q < JB; ++q) {
-        const int u = min((wave + 4 * q) * 16 + jl, H - 1);
+        const int u = min((wave + NW * q) * 16 + jl, H - 1);
 #pragma unroll
         for (int c = 0; c < 3; ++c) wrow[q][c] = a.w_hh + (long long)(c * H + u) * H;
     }
@@ -87,8 +90,8 @@ __global__ __launch_bounds__(GRU_THREADS, 1) void gru_seq_fwd_kernel(GruFwdArgs 
         float4 gi4[JB][3];
 #pragma unroll
         for (int q = 0; q < JB; ++q) {
-            const int u0 = (wave + 4 * q) * 16 + 4 * g;
-            const bool ok = (wave + 4 * q) < nblk && u0 < H && row_ok;
+            const int u0 = (wave + NW * q) * 16 + 4 * g;
+            const bool ok = (wave + NW * q) < nblk && u0 < H && row_ok;
             const float *p = a.gi + (ok ? ((long long)t * B + brow) * H3 + u0 : 0);
 #pragma unroll
             for (int c = 0; c < 3; ++c) gi4[q][c] = *reinterpret_cast<const float4 *>(p + (ok ? c * H : 0));
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(GRU_THREADS, 1) void gru_seq_fwd_kernel(GruFwdArgs 
             const int k = min(16 * kb + 4 * g, H - 4);   // the padded k tail multiplies zero rows of h
 #pragma unroll
             for (int q = 0; q < JB; ++q)
-                if (wave + 4 * q < nblk) {
+                if (wave + NW * q < nblk) {
 #pragma unroll
                     for (int c = 0; c < 3; ++c) w[q][c] = *reinterpret_cast<const float4 *>(wrow[q][c] + k);
                 }
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(GRU_THREADS, 1) void gru_seq_fwd_kernel(GruFwdArgs 
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int q = 0; q < JB; ++q)
-                    if (wave + 4 * q < nblk) {
+                    if (wave + NW * q < nblk) {
 #pragma unroll
                         for (int c = 0; c < 3; ++c) {
                             const float wv = e == 0 ? w[q][c].x : (e == 1 ? w[q][c].y : (e == 2 ? w[q][c].z : w[q][c].w));
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(GRU_THREADS, 1) void gru_seq_fwd_kernel(GruFwdArgs 
         // gates on the accumulators: lane = batch row, registers = units u0 .. u0+3
 #pragma unroll
         for (int q = 0; q < JB; ++q) {
-            const int blk = wave + 4 * q;
+            const int blk = wave + NW * q;
             const int u0 = blk * 16 + 4 * g;
             if (blk >= nblk || u0 >= H) continue;
             float4 b3[3];
@@ -199,8 +202,9 @@ struct GruBwdArgs {
     float *dh0;           // [B,H]
 };
 
-template <int JB>
-__global__ __launch_bounds__(GRU_THREADS, 1) void gru_seq_bwd_kernel(GruBwdArgs a) {
+template <int JB, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void gru_seq_bwd_kernel(GruBwdArgs a) {
+    constexpr int GRU_THREADS = 64 * NW;
     extern __shared__ __align__(16) float lds[];
     const int H = a.H, B = a.B, H3 = 3 * a.H;
     const int nblk = (H + 15) >> 4;
@@ -223,7 +227,7 @@ __global__ __launch_bounds__(GRU_THREADS, 1) void gru_seq_bwd_kernel(GruBwdArgs 
     const bool row_ok = brow < B;
     const float *wrow[JB];                      // A operand rows: unit 16 blk + jl of W_hh^T (clamped)
 #pragma unroll
-    for (int q = 0; q < JB; ++q) wrow[q] = a.w_hh_t + (long long)min((wave + 4 * q) * 16 + jl, H - 1) * H3;
+    for (int q = 0; q < JB; ++q) wrow[q] = a.w_hh_t + (long long)min((wave + NW * q) * 16 + jl, H - 1) * H3;
 
     // saved values of one step in the register layout of the gate arithmetic: for row brow, units
     // u0 .. u0+3 of every block this wave owns (16 bytes per array)
@@ -233,8 +237,8 @@ __global__ __launch_bounds__(GRU_THREADS, 1) void gru_seq_bwd_kernel(GruBwdArgs 
     auto fetch = [&](Saved &s, int t) {
 #pragma unroll
         for (int q = 0; q < JB; ++q) {
-            const int u0 = (wave + 4 * q) * 16 + 4 * g;
-            const bool ok = (wave + 4 * q) < nblk && u0 < H && row_ok;
+            const int u0 = (wave + NW * q) * 16 + 4 * g;
+            const bool ok = (wave + NW * q) < nblk && u0 < H && row_ok;
             const long long o3 = ok ? ((long long)t * B + brow) * H3 + u0 : 0;
             const long long o1 = ok ? ((long long)t * B + brow) * H + u0 : 0;
             s.rr[q] = *reinterpret_cast<const float4 *>(a.gates + o3);
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(GRU_THREADS, 1) void gru_seq_bwd_kernel(GruBwdArgs 
             for (int r = 0; r < 4; ++r) dzh[q][r] = 0.f;
 #pragma unroll
         for (int q = 0; q < JB; ++q) {
-            const int blk = wave + 4 * q;
+            const int blk = wave + NW * q;
             const int u0 = blk * 16 + 4 * g;
             if (blk >= nblk || u0 >= H) continue;
             const float rr[4] = {cur.rr[q].x, cur.rr[q].y, cur.rr[q].z, cur.rr[q].w};
@@ -298,14 +302,14 @@ __global__ __launch_bounds__(GRU_THREADS, 1) void gru_seq_bwd_kernel(GruBwdArgs 
         f32x4 acc[JB];
 #pragma unroll
         for (int q = 0; q < JB; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        constexpr int G = 4;            // k blocks per group; one group of W_hh^T fragments travels ahead
+        constexpr int G = NW > 4 ? 3 : 4;   // k blocks per group; one group of W_hh^T fragments travels ahead (128 registers per lane at 16 waves)
         auto load_w = [&](float4 (&w)[G][JB], int kb0) {
 #pragma unroll
             for (int u = 0; u < G; ++u) {
                 const int k = min(16 * (kb0 + u) + 4 * g, H3 - 4);   // the padded k tail multiplies zero rows
 #pragma unroll
                 for (int q = 0; q < JB; ++q)
-                    if (wave + 4 * q < nblk) w[u][q] = *reinterpret_cast<const float4 *>(wrow[q] + k);
+                    if (wave + NW * q < nblk) w[u][q] = *reinterpret_cast<const float4 *>(wrow[q] + k);
             }
         };
         auto multiply = [&](const float4 (&w)[G][JB], int kb0) {
@@ -319,7 +323,7 @@ __global__ __launch_bounds__(GRU_THREADS, 1) void gru_seq_bwd_kernel(GruBwdArgs 
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
                     for (int q = 0; q < JB; ++q)
-                        if (wave + 4 * q < nblk) {
+                        if (wave + NW * q < nblk) {
                             const float wv = e == 0 ? w[u][q].x : (e == 1 ? w[u][q].y : (e == 2 ? w[u][q].z : w[u][q].w));
                             acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, dv[e], acc[q], 0, 0, 0);
                         }
@@ -342,8 +346,8 @@ __global__ __launch_bounds__(GRU_THREADS, 1) void gru_seq_bwd_kernel(GruBwdArgs 
     }
 #pragma unroll
     for (int q = 0; q < JB; ++q) {
-        const int u0 = (wave + 4 * q) * 16 + 4 * g;
-        if (wave + 4 * q >= nblk || u0 >= H || !row_ok) continue;
+        const int u0 = (wave + NW * q) * 16 + 4 * g;
+        if (wave + NW * q >= nblk || u0 >= H || !row_ok) continue;
         *reinterpret_cast<float4 *>(a.dh0 + (long long)brow * H + u0) = make_float4(dh[q][0], dh[q][1], dh[q][2], dh[q][3]);
     }
 }
@@ -369,15 +373,17 @@ extern "C" int psvae_gru_seq_fwd(int T, int B, int H, const float *gi, const flo
                       psvae_aligned16(ghn) && psvae_aligned16(b_hh),
                   PSVAE_EINVAL, "%s: every array must be 16-byte aligned", fn);
     GruFwdArgs a{T, B, H, gi, h0, w_hh, b_hh, hall, gates, ghn};
-    const int KP = (H + 15) & ~15, nblk = KP / 16, jb = psvae_cdiv(nblk, 4);
+    const int KP = (H + 15) & ~15, nblk = KP / 16;
+    const int nw = nblk > 4 ? GRU_WAVES_WIDE : 4, jb = psvae_cdiv(nblk, nw);
     const size_t lds = 2 * (size_t)KP * GRU_LD * sizeof(float);
-    const dim3 grid(psvae_cdiv(B, GRU_ROWS)), blk(GRU_THREADS);
+    const dim3 grid(psvae_cdiv(B, GRU_ROWS)), blk(64 * nw);
     hipStream_t s = (hipStream_t)stream;
-    switch (jb) {
-        case 1: hipLaunchKernelGGL(gru_seq_fwd_kernel<1>, grid, blk, lds, s, a); break;
-        case 2: hipLaunchKernelGGL(gru_seq_fwd_kernel<2>, grid, blk, lds, s, a); break;
-        case 3: hipLaunchKernelGGL(gru_seq_fwd_kernel<3>, grid, blk, lds, s, a); break;
-        default: hipLaunchKernelGGL(gru_seq_fwd_kernel<4>, grid, blk, lds, s, a); break;
+    if (nw == 4) {
+        hipLaunchKernelGGL((gru_seq_fwd_kernel<1, 4>), grid, blk, lds, s, a);
+    } else {
+        static_assert(PSVAE_GRU_SEQ_MAX_H <= 16 * GRU_WAVES_WIDE, "one block of 16 units per wave");
+        (void)jb;
+        hipLaunchKernelGGL((gru_seq_fwd_kernel<1, GRU_WAVES_WIDE>), grid, blk, lds, s, a);
     }
     PSVAE_CHECK_LAUNCH(fn);
     return PSVAE_OK;
@@ -396,24 +402,25 @@ extern "C" int psvae_gru_seq_bwd(int T, int B, int H, const float *gates, const 
                       psvae_aligned16(g_out) && psvae_aligned16(dgi) && psvae_aligned16(dgh) && psvae_aligned16(dh0),
                   PSVAE_EINVAL, "%s: every array must be 16-byte aligned", fn);
     GruBwdArgs a{T, B, H, gates, ghn, hall, g_out, w_hh_t, dgi, dgh, dh0};
-    const int nblk = (H + 15) / 16, jb = psvae_cdiv(nblk, 4);
+    const int nblk = (H + 15) / 16;
+    const int nw = nblk > 4 ? GRU_WAVES_WIDE : 4, jb = psvae_cdiv(nblk, nw);
     const int K3P = (3 * H + 15) & ~15;
     const size_t lds = 2 * (size_t)K3P * GRU_LD * sizeof(float);
     PSVAE_REQUIRE(lds <= 160 * 1024, PSVAE_ETOOLARGE, "%s: LDS need %zu", fn, lds);
-    const dim3 grid(psvae_cdiv(B, GRU_ROWS)), blk(GRU_THREADS);
+    const dim3 grid(psvae_cdiv(B, GRU_ROWS)), blk(64 * nw);
     hipStream_t s = (hipStream_t)stream;
-#define PSVAE_GRU_BWD(JB)                                                                                        \
+#define PSVAE_GRU_BWD(JB, NW)                                                                                    \
     do {                                                                                                         \
         if (lds > 64 * 1024)                                                                                     \
-            (void)hipFuncSetAttribute((const void *)gru_seq_bwd_kernel<JB>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+            (void)hipFuncSetAttribute((const void *)gru_seq_bwd_kernel<JB, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       (int)lds);                                                                 \
-        hipLaunchKernelGGL(gru_seq_bwd_kernel<JB>, grid, blk, lds, s, a);                                        \
+        hipLaunchKernelGGL((gru_seq_bwd_kernel<JB, NW>), grid, blk, lds, s, a);                                  \
     } while (0)
-    switch (jb) {
-        case 1: PSVAE_GRU_BWD(1); break;
-        case 2: PSVAE_GRU_BWD(2); break;
-        case 3: PSVAE_GRU_BWD(3); break;
-        default: PSVAE_GRU_BWD(4); break;
+    if (nw == 4) {
+        PSVAE_GRU_BWD(1, 4);
+    } else {
+        (void)jb;
+        PSVAE_GRU_BWD(1, GRU_WAVES_WIDE);
     }
 #undef PSVAE_GRU_BWD
     PSVAE_CHECK_LAUNCH(fn);
