@@ -14,6 +14,9 @@
 //    is read from HBM exactly once, and per k-step a wave issues TN MFMAs for TN+1 LDS reads.
 //    Global loads are 16 B per lane and the next k-tile is in flight (registers) while the
 //    current one is multiplied.  Needs 16-byte aligned operands (checked on the host).
+//    Products too small to fill the chip with panels take 64 x 64 tiles of the same kernel, and the
+//    products of a small batch (at most 512 tiles of 32 x 32) its latency form: one 32 x 32 tile per
+//    workgroup, the four waves splitting K, all of a short K requested at once (gemm_panel.h).
 //  * gemm_generic_kernel — any strides / alignment, 64x64 tiles, scalar loads.
 //
 // LDS tiles are k-major (T[k][x]): an MFMA operand fetch is one conflict-free ds_read_b32 per
@@ -229,6 +232,10 @@ int resolve_split(int M, int N, int K, int split_k) {
 #define PSVAE_TILE64_BELOW 256   // (the -D override exists for A/B builds only)
 #endif
 constexpr int TILE64_BELOW_BLOCKS = PSVAE_TILE64_BELOW;
+#ifndef PSVAE_2X2_MIN_BLOCKS
+#define PSVAE_2X2_MIN_BLOCKS 256
+#endif
+constexpr int TWO_BY_TWO_MIN_BLOCKS = PSVAE_2X2_MIN_BLOCKS;
 int tile64_split(int M, int n_ext, int K) {
     const long long tiles = (long long)psvae_cdiv(M, 64) * psvae_cdiv(n_ext, 64);
     long long s = 256 / tiles;
@@ -236,6 +243,12 @@ int tile64_split(int M, int n_ext, int K) {
     if (s > by_k) s = by_k;
     return s < 1 ? 1 : (int)s;
 }
+
+// Products of at most this many 32 x 32 tiles (two small workgroups per CU) take the latency form.
+#ifndef PSVAE_TILE32_MAX_TILES
+#define PSVAE_TILE32_MAX_TILES 512   // (the -D override exists for A/B builds only; 0: never)
+#endif
+constexpr int TILE32_MAX_TILES = PSVAE_TILE32_MAX_TILES;
 
 bool vec_ok(const float *p, long long s_major) {
     return p == nullptr || (psvae_aligned16(p) && s_major % 4 == 0);
@@ -304,9 +317,11 @@ static int gemm_impl(int M, int N, int K, const float *A, const float *amask, in
     const bool panel = a_vec && b_vec && (!rowsum || !b_kc) && M >= 32;
     int nc = 1, bn = 32, tn = 1;
     if (panel) panel_shape(n_ext, nc, bn, tn);
-    const bool two_by_two = panel && !a_kc && !b_kc && prefer_2x2(M, n_ext);
     const int split_asked = split_k;
     split_k = resolve_split(M, N, K, split_k);
+    // (a short K leaves the 64 x 320 panels on a handful of CUs with long serial k loops: 64 x 64 tiles then)
+    const bool two_by_two = panel && !a_kc && !b_kc && prefer_2x2(M, n_ext) &&
+                            (long long)psvae_cdiv(M, 64) * split_k >= TWO_BY_TWO_MIN_BLOCKS;
     // 64 x 64 tiles where the panels (with their K split) would leave the chip mostly idle
     const bool tile64 = panel && !two_by_two && (long long)psvae_cdiv(M, 128) * nc * split_k < TILE64_BELOW_BLOCKS;
     if (tile64 && split_asked == 0) split_k = tile64_split(M, n_ext, K);
@@ -339,7 +354,13 @@ static int gemm_impl(int M, int N, int K, const float *A, const float *amask, in
     if (tile64) {
         g.nt_m = psvae_cdiv(M, 64), g.nt_n = psvae_cdiv(g.n_ext, 64), g.bn = 64, g.wn = 2;
         const long long blocks = (long long)psvae_cdiv((long long)g.nt_m * split_k, 8) * 8 * g.nt_n;
-        launch_tile64(g, a_kc, b_kc, dim3((unsigned)blocks), s);
+        if ((long long)psvae_cdiv(M, 32) * psvae_cdiv(g.n_ext, 32) * split_k <= TILE32_MAX_TILES) {
+            g.nt_m = psvae_cdiv(M, 32), g.nt_n = psvae_cdiv(g.n_ext, 32), g.bn = 32, g.wn = 1;
+            const long long blocks32 = (long long)psvae_cdiv((long long)g.nt_m * split_k, 8) * 8 * g.nt_n;
+            launch_tile32(g, a_kc, b_kc, dim3((unsigned)blocks32), s);
+        } else {
+            launch_tile64(g, a_kc, b_kc, dim3((unsigned)blocks), s);
+        }
     } else if (panel) {
         g.nt_m = psvae_cdiv(M, 128), g.nt_n = nc, g.bn = bn, g.wn = 1;
         if (two_by_two) {

@@ -103,6 +103,9 @@ void launch_panel_classes(const GemmArgs &g, int tn, dim3 grid, hipStream_t s);
 #endif
 constexpr int TILE64_BK = PSVAE_TILE64_BK;
 void launch_tile64(const GemmArgs &g, bool a_kc, bool b_kc, dim3 grid, hipStream_t s);
+// 32 x 32 tiles whose TILE64_KG waves split K, the latency form (tile32_inst.hip)
+constexpr int TILE64_KG = 4;
+void launch_tile32(const GemmArgs &g, bool a_kc, bool b_kc, dim3 grid, hipStream_t s);
 
 // ---- tall-K weight-gradient kernel (gemm_tallk.hip)
 constexpr int TK_THREADS = 512, TK_BK = 16, TK_LDA = 304, TK_LDB = 176, TK_T = 5, TK_MAX = 304, TK_STAGES = 3;

@@ -2,13 +2,16 @@
 #pragma once
 #include "gemm_common.h"
 
+#include <type_traits>
+
 namespace psvae_gemm {
 
 // ------------------------------------------------------------------------------------------
 // Fast path: 128 x (32*TN) panel per workgroup, vector loads.
 // ------------------------------------------------------------------------------------------
-template <int BX, int BK, bool KCONTIG>
+template <int BX, int BK, bool KCONTIG, int NT = psvae_gemm::THREADS>
 struct TileLoader {
+    static constexpr int THREADS = NT;                                // threads that share the tile
     static constexpr int ITEMS = BX * BK / 4;                         // float4 items per tile
     static constexpr int PER_THREAD = (ITEMS + THREADS - 1) / THREADS;
     static constexpr int STRIDE = KCONTIG ? BX + 1 : BX + 4;          // LDS row stride (floats)
@@ -88,9 +91,16 @@ struct TileLoader {
 // WN = 1: the 4 waves stack along M (128-row panel, 32*TN columns).  WN = 2: a 2 x 2 wave grid
 // (64 rows x 64*TN columns), for products whose M fits 64-row panels with less padding and, with
 // TN = 1 (64 x 64 tiles, tile64_inst.hip), for products too small to fill the chip with panels.
-template <int TN, int BK, bool A_KC, bool B_KC, bool MASK, bool ONES, int WN = 1, bool CLS = false>
-__global__ __launch_bounds__(THREADS, (MASK || WN > 1 || TN > 5) ? 2 : PSVAE_PANEL_OCC) void gemm_panel_kernel(GemmArgs g) {
-    constexpr int WM = 4 / WN, BM = 32 * WM, BN = 32 * TN * WN;
+//
+// KG > 1: the latency form for the products of a small batch - a 32 x 32 tile per workgroup, its four waves
+// splitting K.  Every kernel starts with cold caches and a CU has a bounded number of requests in flight, so a
+// short product on few CUs takes as long as its operand bytes per CU take to arrive: small tiles put the same
+// bytes on four times as many CUs.  All threads stage the 64-deep k-tiles (five of them requested ahead, which
+// is all of K = 320 at once), wave q multiplies k-steps 16 q .. 16 q + 15 of every tile, the four partial tiles
+// are summed through LDS in a fixed order and wave 0 runs the epilogue.
+template <int TN, int BK, bool A_KC, bool B_KC, bool MASK, bool ONES, int WN = 1, bool CLS = false, int KG = 1>
+__global__ __launch_bounds__(THREADS, KG > 1 ? 1 : ((MASK || WN > 1 || TN > 5) ? 2 : PSVAE_PANEL_OCC)) void gemm_panel_kernel(GemmArgs g) {
+    constexpr int WM = KG > 1 ? 1 : 4 / WN, BM = 32 * WM, BN = 32 * TN * WN;
     using LA = TileLoader<BM, BK, A_KC>;
     using LB = TileLoader<BN, BK, B_KC>;
     constexpr int A_FLOATS = BK * LA::STRIDE, B_FLOATS = BK * LB::STRIDE;
@@ -99,7 +109,9 @@ __global__ __launch_bounds__(THREADS, (MASK || WN > 1 || TN > 5) ? 2 : PSVAE_PAN
     // tiles of small products (one workgroup per CU at best, so nothing else hides a k-tile's loads)
     constexpr int NBUF = ((PSVAE_PANEL_NBUF == 2 || (WN == 2 && TN == 1)) && 2 * STAGE_FLOATS * 4 <= 76 * 1024) ? 2 : 1;
     constexpr int EPI_STRIDE = 36, EPI_FLOATS = 4 * 32 * EPI_STRIDE;   // one 32x32 tile per wave
-    constexpr int LDS_FLOATS = NBUF * STAGE_FLOATS > EPI_FLOATS ? NBUF * STAGE_FLOATS : EPI_FLOATS;
+    constexpr int RED_FLOATS = (KG - 1) * 16 * 64;   // partial tiles of the waves 1 .. KG-1
+    constexpr int LDS_FLOATS = KG > 1 ? (EPI_FLOATS + RED_FLOATS > 2 * STAGE_FLOATS ? EPI_FLOATS + RED_FLOATS : 2 * STAGE_FLOATS)
+                                      : (NBUF * STAGE_FLOATS > EPI_FLOATS ? NBUF * STAGE_FLOATS : EPI_FLOATS);
     __shared__ __align__(16) float smem[LDS_FLOATS];
     float *As = smem, *Bs = smem + A_FLOATS;
 
@@ -108,7 +120,7 @@ __global__ __launch_bounds__(THREADS, (MASK || WN > 1 || TN > 5) ? 2 : PSVAE_PAN
     const int m0 = tile_m * BM, n0 = tile_n * g.bn;
     const int k_begin = z * g.k_chunk;
     const int k_end = min(g.K, k_begin + g.k_chunk);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = KG > 1 ? 0 : tid >> 6;
     const int wave_m = wave % WM, wave_n = wave / WM;
     const int l31 = lane & 31, lhi = lane >> 5;
     const int ones_x = g.N;
@@ -122,6 +134,7 @@ __global__ __launch_bounds__(THREADS, (MASK || WN > 1 || TN > 5) ? 2 : PSVAE_PAN
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
+    if constexpr (KG == 1) {
     float4 ra[LA::PER_THREAD], rb[LB::PER_THREAD], rma[MASK ? LA::PER_THREAD : 1], rmb[1];
     if (k_begin < k_end) {
         LA::template load<MASK>(ra, rma, g.A, g.amask, g.sa_m, g.sa_k, m0, k_begin, g.M, k_end, tid);
@@ -221,6 +234,64 @@ __global__ __launch_bounds__(THREADS, (MASK || WN > 1 || TN > 5) ? 2 : PSVAE_PAN
             __syncthreads();
             cur ^= 1;
         }
+    }
+    } else {
+        static_assert(KG == 1 || (KG == 4 && TN == 1 && WN == 1 && !CLS), "latency form: 32 x 32 tiles, four waves");
+        constexpr int PA = LA::PER_THREAD, PB = LB::PER_THREAD;
+        const int grp = tid >> 6;
+        const bool a_inside = m0 + BM <= g.M, b_inside = n0 + BN <= n_lim;
+        constexpr int D = 5, KSTEPS = BK / KG;
+        float4 fa[D][PA], fb[D][PB], fm[D][MASK ? PA : 1], none[1];
+        const int n_tiles = (k_end - k_begin + BK - 1) / BK;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            LA::template load<MASK>(fa[d], fm[d], g.A, g.amask, g.sa_m, g.sa_k, m0, k_begin + d * BK, g.M, k_end, tid);
+            LB::template load<false>(fb[d], none, g.B, nullptr, g.sb_n, g.sb_k, n0, k_begin + d * BK, n_lim, k_end, tid);
+        }
+        const float *a_rd = As + (lhi + grp * KSTEPS) * LA::STRIDE + l31;
+        const float *b_rd = Bs + (lhi + grp * KSTEPS) * LB::STRIDE + l31;
+        for (int t0 = 0; t0 < n_tiles; t0 += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const int t = t0 + d, k0 = k_begin + t * BK;
+                if (t >= n_tiles) break;   // block-uniform
+                // a tile goes to the LDS stage of its parity: one barrier per tile
+                float *as = As + (t & 1) * STAGE_FLOATS, *bs = Bs + (t & 1) * STAGE_FLOATS;
+                if (k0 + BK <= k_end && a_inside)
+                    LA::template store<MASK, false, true>(as, fa[d], fm[d], m0, k0, g.M, k_end, -1, tid);
+                else
+                    LA::template store<MASK, false>(as, fa[d], fm[d], m0, k0, g.M, k_end, -1, tid);
+                if (k0 + BK <= k_end && b_inside)
+                    LB::template store<false, ONES, true>(bs, fb[d], none, n0, k0, n_lim, k_end, ones_x, tid);
+                else
+                    LB::template store<false, ONES>(bs, fb[d], none, n0, k0, n_lim, k_end, ones_x, tid);
+                if (k0 + D * BK < k_end) {   // block-uniform
+                    LA::template load<MASK>(fa[d], fm[d], g.A, g.amask, g.sa_m, g.sa_k, m0, k0 + D * BK, g.M, k_end, tid);
+                    LB::template load<false>(fb[d], none, g.B, nullptr, g.sb_n, g.sb_k, n0, k0 + D * BK, n_lim, k_end, tid);
+                }
+                __syncthreads();
+                const float *ar = a_rd + (t & 1) * STAGE_FLOATS, *br = b_rd + (t & 1) * STAGE_FLOATS;
+                float av[KSTEPS / 2], bv[KSTEPS / 2];
+#pragma unroll
+                for (int q = 0; q < KSTEPS / 2; ++q) av[q] = ar[2 * q * LA::STRIDE], bv[q] = br[2 * q * LB::STRIDE];
+#pragma unroll
+                for (int q = 0; q < KSTEPS / 2; ++q)   // (rows past the end of K hold zeros)
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc[0], 0, 0, 0);
+            }
+        }
+        __syncthreads();   // the partial tiles below reuse the operand stages
+        float *red = smem + EPI_FLOATS;
+        if (grp > 0) {
+            float *r = red + (grp - 1) * 16 * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) r[i * 64] = acc[0][i];
+        }
+        __syncthreads();
+        if (grp > 0) return;
+#pragma unroll
+        for (int q = 0; q < KG - 1; ++q)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[0][i] += red[(q * 16 + i) * 64 + lane];
     }
 
     // Epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) +

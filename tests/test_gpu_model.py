@@ -204,11 +204,24 @@ def test_default_width_model_against_reference_golden(tokenizer):
     opt.max_norm = 10.0
     opt.step()
     np.testing.assert_allclose(opt.grad_norm.item(), gold['grad_total_norm'], rtol=1e-5)
+    # Adam's first step moves an entry by lr g / (|g| + eps): where |g| is within a few orders of eps = 1e-8 the
+    # step amplifies a gradient error dg by lr eps / (|g| + eps)^2.  The bound of an entry is GOLD_REL of the
+    # tensor's largest entry plus that amplification of the gradient error allowed above (never more than the
+    # 2 lr a step can differ by); the count of entries that needed the second term is printed.
+    lr, adam_eps, widened = float(opt.param_groups[0]['lr']), 1e-8, 0
     for k, v in model.state_dict().items():
         want = gold[f'after_step_sample/{k}']
         got = v.reshape(-1)[::97].cpu().numpy()
-        assert np.abs(got - want).max() <= GOLD_REL * max(np.abs(want).max(), 1e-30), f'after step {k}'
-    print(f'default widths vs the reference: largest sampled gradient error {worst[0]:.2e} of its tensor\'s largest entry ({worst[1]})')
+        err = np.abs(got - want)
+        base = GOLD_REL * max(np.abs(want).max(), 1e-30)
+        bound = np.full_like(err, base)
+        if f'gradsample/{k}' in gold:
+            g = np.abs(gold[f'gradsample/{k}'])
+            bound = base + np.minimum(2 * lr, lr * adam_eps * GOLD_REL * float(gold[f'gradmax/{k}']) / (g + adam_eps) ** 2)
+        assert (err <= bound).all(), f'after step {k}: {err.max():.3e} vs {base:.3e}'
+        widened += int((err > base).sum())
+    print(f'default widths vs the reference: largest sampled gradient error {worst[0]:.2e} of its tensor\'s largest entry ({worst[1]}); '
+          f'{widened} sampled entries after the step lie within the bound only with Adam\'s amplification of a near-zero gradient')
 
 
 def test_default_width_batch_256_against_oracle(tokenizer):
