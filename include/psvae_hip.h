@@ -415,6 +415,32 @@ int psvae_pair_combine_bwd(int B, int F, const float *g_out, int ldg, const floa
                            float *g_ab, int ldab, float *g_c, int ldc, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * The scalar tail of the step and the block table of the atom features, one launch each (at batch 32 the
+ * torch expressions they stand for are five to twelve launches of a step that is a chain of ~200).
+ *
+ * psvae_block_table: the three embedding tables of embed_atom (src/modules/vae_piece_decoder.py:65-69:
+ *   atom [na,da], piece [np,dp], position [nq,dq]) as one matrix Z [na+np+nq, da+dp+dq+4], table k in its own
+ *   column block, zeros elsewhere and a one in column da+dp+dq of the atom rows, so that
+ *   Z . [W | b | 0]^T is node_trans (src/modules/encoder.py:54) of every table row with the bias on the atom rows.
+ * psvae_mse_selected_fwd/bwd: nn.MSELoss() between the predictor's output pred [B,k] and the selected property
+ *   columns props[:, sel] (src/pl_models/ps_vae_model.py:55-57): loss = mean (pred - props[:, sel])^2 with the
+ *   differences kept in diff [B*k]; backward g_pred = g * 2 diff / (B k), g a device scalar.  sel: int64 [k].
+ * psvae_loss_mix_fwd/bwd: weighted_loss (src/pl_models/ps_vae_model.py:71-74):
+ *   out = alpha rec + (1 - alpha) pred + beta kl on device scalars, every product and sum rounded on its own;
+ *   beta comes from beta_dev when that is not NULL (a recorded step reads it from device memory).  Backward
+ *   writes g3 = g * (alpha, 1 - alpha, beta).
+ * ---------------------------------------------------------------------------------- */
+int psvae_block_table(int na, int da, int np, int dp, int nq, int dq, const float *ea, const float *ep,
+                      const float *eq, float *Z, void *stream);
+int psvae_mse_selected_fwd(int B, int k, const float *pred, int ld_pred, const float *props, int ld_props,
+                           const int64_t *sel, float *diff, float *loss, void *stream);
+int psvae_mse_selected_bwd(int n, const float *diff, const float *g, float *g_pred, void *stream);
+int psvae_loss_mix_fwd(const float *rec, const float *pred, const float *kl, float alpha, float one_minus_alpha,
+                       float beta, const float *beta_dev, float *out, void *stream);
+int psvae_loss_mix_bwd(const float *g, float alpha, float one_minus_alpha, float beta, const float *beta_dev,
+                       float *g3, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * Two Linear layers with no activation between them as one affine map — the link
  * predictor's MLP output layer followed by the class layer
  * (src/modules/vae_piece_decoder.py:42-46, 110):

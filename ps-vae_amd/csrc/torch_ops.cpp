@@ -420,6 +420,52 @@ void onehot(const Tensor &ids, Tensor out) {
                            cur_stream(out)), fn);
 }
 
+void block_table(const Tensor &ea, const Tensor &ep, const Tensor &eq, Tensor Z) {
+    PSVAE_ON_DEVICE("psvae::block_table", p(ea), p(ep), p(eq), p(Z));
+    const char *fn = "psvae_block_table";
+    TORCH_CHECK(ea.dim() == 2 && ep.dim() == 2 && eq.dim() == 2 && Z.dim() == 2 &&
+                    Z.size(0) == ea.size(0) + ep.size(0) + eq.size(0) && Z.size(1) == ea.size(1) + ep.size(1) + eq.size(1) + 4,
+                fn, ": Z must be [rows of the three tables, their widths + 4]");
+    check(psvae_block_table((int)ea.size(0), (int)ea.size(1), (int)ep.size(0), (int)ep.size(1), (int)eq.size(0), (int)eq.size(1),
+                            f32c(ea, fn), f32c(ep, fn), f32c(eq, fn), const_cast<float *>(f32c(Z, fn)), cur_stream(Z)), fn);
+}
+
+void mse_selected_fwd(const Tensor &pred, const Tensor &props, const Tensor &sel, Tensor diff, Tensor loss) {
+    PSVAE_ON_DEVICE("psvae::mse_selected_fwd", p(pred), p(props), p(sel), p(diff), p(loss));
+    const char *fn = "psvae_mse_selected_fwd";
+    TORCH_CHECK(pred.dim() == 2 && props.dim() == 2 && props.size(0) == pred.size(0) && sel.numel() == pred.size(1) &&
+                    sel.scalar_type() == at::kLong && sel.is_contiguous() && diff.numel() == pred.numel() && loss.numel() == 1,
+                fn, ": pred [B,k], props [B,*], sel int64 [k], diff [B*k], loss scalar");
+    check(psvae_mse_selected_fwd((int)pred.size(0), (int)pred.size(1), f32(pred, fn), (int)row_stride(pred, fn), f32(props, fn),
+                                 (int)row_stride(props, fn), sel.const_data_ptr<int64_t>(), const_cast<float *>(f32c(diff, fn)),
+                                 f32_mut(loss, fn), cur_stream(loss)), fn);
+}
+
+void mse_selected_bwd(const Tensor &diff, const Tensor &g, Tensor g_pred) {
+    PSVAE_ON_DEVICE("psvae::mse_selected_bwd", p(diff), p(g), p(g_pred));
+    const char *fn = "psvae_mse_selected_bwd";
+    TORCH_CHECK(g.numel() == 1 && g_pred.numel() == diff.numel(), fn, ": g scalar, g_pred like diff");
+    check(psvae_mse_selected_bwd((int)diff.numel(), f32c(diff, fn), f32(g, fn), const_cast<float *>(f32c(g_pred, fn)),
+                                 cur_stream(g_pred)), fn);
+}
+
+void loss_mix_fwd(const Tensor &rec, const Tensor &pred, const Tensor &kl, double alpha, double one_minus_alpha, double beta,
+                  const OptTensor &beta_dev, Tensor out) {
+    PSVAE_ON_DEVICE("psvae::loss_mix_fwd", p(rec), p(pred), p(kl), p(beta_dev), p(out));
+    const char *fn = "psvae_loss_mix_fwd";
+    TORCH_CHECK(rec.numel() == 1 && pred.numel() == 1 && kl.numel() == 1 && out.numel() == 1, fn, ": scalars expected");
+    check(psvae_loss_mix_fwd(f32(rec, fn), f32(pred, fn), f32(kl, fn), (float)alpha, (float)one_minus_alpha, (float)beta,
+                             f32(beta_dev, fn), f32_mut(out, fn), cur_stream(out)), fn);
+}
+
+void loss_mix_bwd(const Tensor &g, double alpha, double one_minus_alpha, double beta, const OptTensor &beta_dev, Tensor g3) {
+    PSVAE_ON_DEVICE("psvae::loss_mix_bwd", p(g), p(beta_dev), p(g3));
+    const char *fn = "psvae_loss_mix_bwd";
+    TORCH_CHECK(g.numel() == 1 && g3.numel() == 3 && g3.is_contiguous(), fn, ": g scalar, g3 [3]");
+    check(psvae_loss_mix_bwd(f32(g, fn), (float)alpha, (float)one_minus_alpha, (float)beta, f32(beta_dev, fn), f32_mut(g3, fn),
+                             cur_stream(g3)), fn);
+}
+
 void affine_merge_fwd(const Tensor &w_last, const OptTensor &b_last, const Tensor &w_out, const OptTensor &b_out, Tensor w_eff,
                       Tensor b_eff) {
     PSVAE_ON_DEVICE("psvae::affine_merge_fwd", p(w_last), p(b_last), p(w_out), p(b_out), p(w_eff), p(b_eff));
@@ -517,6 +563,13 @@ TORCH_LIBRARY(psvae, m) {
     m.def("keyed_row_sum(Tensor g, Tensor perm, Tensor row_off, Tensor unit_off, int chunk, Tensor(a!) out) -> ()",
           &keyed_row_sum);
     m.def("onehot(Tensor ids, Tensor(a!) out) -> ()", &onehot);
+    m.def("block_table(Tensor ea, Tensor ep, Tensor eq, Tensor(a!) Z) -> ()", &block_table);
+    m.def("mse_selected_fwd(Tensor pred, Tensor props, Tensor sel, Tensor(a!) diff, Tensor(b!) loss) -> ()", &mse_selected_fwd);
+    m.def("mse_selected_bwd(Tensor diff, Tensor g, Tensor(a!) g_pred) -> ()", &mse_selected_bwd);
+    m.def("loss_mix_fwd(Tensor rec, Tensor pred, Tensor kl, float alpha, float one_minus_alpha, float beta, Tensor? beta_dev, "
+          "Tensor(a!) out) -> ()", &loss_mix_fwd);
+    m.def("loss_mix_bwd(Tensor g, float alpha, float one_minus_alpha, float beta, Tensor? beta_dev, Tensor(a!) g3) -> ()",
+          &loss_mix_bwd);
     m.def("affine_merge_fwd(Tensor w_last, Tensor? b_last, Tensor w_out, Tensor? b_out, Tensor(a!) w_eff, Tensor(b!) b_eff) -> ()",
           &affine_merge_fwd);
     m.def("affine_merge_bwd(Tensor w_last, Tensor w_out, Tensor? b_out, Tensor g_w_eff, Tensor g_b_eff, Tensor(a!) g_w_last, "

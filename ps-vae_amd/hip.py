@@ -58,6 +58,11 @@ _SIGNATURES = {
                                 _p, _p, _p, _c_int, _c_int, _c_int, _p, _c_size, _p]),
     'psvae_pair_combine_fwd': (_c_int, [_c_int, _c_int, _p, _c_int, _p, _c_int, _p, _c_int, _p, _p, _p, _c_int, _p,
                                         _c_int, _p]),
+    'psvae_block_table': (_c_int, [_c_int] * 6 + [_p, _p, _p, _p, _p]),
+    'psvae_mse_selected_fwd': (_c_int, [_c_int, _c_int, _p, _c_int, _p, _c_int, _p, _p, _p, _p]),
+    'psvae_mse_selected_bwd': (_c_int, [_c_int, _p, _p, _p, _p]),
+    'psvae_loss_mix_fwd': (_c_int, [_p, _p, _p, _c_f32, _c_f32, _c_f32, _p, _p, _p]),
+    'psvae_loss_mix_bwd': (_c_int, [_p, _c_f32, _c_f32, _c_f32, _p, _p, _p]),
     'psvae_affine_merge_fwd': (_c_int, [_c_int, _c_int, _c_int, _p, _p, _p, _p, _p, _p, _p]),
     'psvae_affine_merge_bwd': (_c_int, [_c_int, _c_int, _c_int, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     'psvae_colsum_workspace_bytes': (_c_size, [_c_int, _c_int]),
@@ -337,6 +342,34 @@ def gemm_bits(M, N, K, A, sa_m, sa_k, B, sb_k, sb_n, C, ldc, bias=None, relu=Fal
     _count()
     with _Prof('gemm_f32_kernel', 2.0 * M * N * K, tag):
         ops().gemm_bits(M, N, K, A, sa_m, sa_k, B, sb_k, sb_n, C, ldc, bias, relu, relu_bits, gate_bits)
+
+
+def block_table(ea, ep, eq, Z):
+    _count()
+    ops().block_table(ea, ep, eq, Z)
+
+
+def mse_selected_fwd(pred, props, sel, diff, loss):
+    _count()
+    ops().mse_selected_fwd(pred, props, sel, diff, loss)
+
+
+def mse_selected_bwd(diff, g, g_pred):
+    _count()
+    ops().mse_selected_bwd(diff, g, g_pred)
+
+
+def loss_mix_fwd(rec, pred, kl, alpha, beta, out):
+    """beta: a Python number or a device scalar."""
+    _count()
+    dev = beta if torch.is_tensor(beta) else None
+    ops().loss_mix_fwd(rec, pred, kl, float(alpha), float(1 - alpha), 0.0 if dev is not None else float(beta), dev, out)
+
+
+def loss_mix_bwd(g, alpha, beta, g3):
+    _count()
+    dev = beta if torch.is_tensor(beta) else None
+    ops().loss_mix_bwd(g, float(alpha), float(1 - alpha), 0.0 if dev is not None else float(beta), dev, g3)
 
 
 def affine_merge_fwd(w_last, b_last, w_out, b_out, w_eff, b_eff):

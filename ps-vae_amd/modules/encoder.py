@@ -26,6 +26,16 @@ class GINEConv(nn.Module):
         return self.nn(ops.gine_aggregate(x, edge_attr, edge_index))
 
 
+_IDENTITY = {}
+
+
+def _identity(n, device):
+    key = (n, device)
+    if key not in _IDENTITY:
+        _IDENTITY[key] = torch.eye(n, dtype=torch.float32, device=device)
+    return _IDENTITY[key]
+
+
 class Encoder(nn.Module):
     def __init__(self, dim_in, num_edge_type, dim_hidden, dim_out, t=4):
         super(Encoder, self).__init__()
@@ -39,6 +49,11 @@ class Encoder(nn.Module):
     def edge_table(self):
         """edge_trans applied to the C one-hot rows: row c = W[:, c] + b (the reference
         multiplies the one-hot edge_attr [E,C] by W^T, src/modules/encoder.py:55)."""
+        if self.edge_trans.weight.is_cuda:
+            # as the product it is in the reference: identity rows through the Linear (one launch forward, one
+            # backward; the sum w + 0 + ... + 0 + b rounds as w + b does)
+            return ops.linear(_identity(self.num_edge_type, self.edge_trans.weight.device), self.edge_trans.weight,
+                              self.edge_trans.bias)
         return self.edge_trans.weight.t() + self.edge_trans.bias
 
     def embed_node(self, x, edge_index, edge_attr=None, want_all=True):

@@ -91,7 +91,7 @@ class VAEPieceDecoder(nn.Module):
         init_hidden = run_linear(self.latent_to_rnn_hidden, z_vecs)
         if rnn.num_layers == 1 and not rnn.bidirectional and rnn.bias:
             # time-major ids -> [T,B,E] embeddings -> HIP GRU
-            ids = pieces[:, :-1].t().contiguous().to(torch.int32)
+            ids = pieces[:, :-1].t().to(torch.int32).contiguous()      # (one kernel: the cast writes the transposed rows)
             table = self.piece_embedding.weight if piece_table is None else piece_table
             emb = ops.embedding(ids, table) if table.shape[1] % 4 == 0 else self.piece_embedding(ids.long())
             hs = ops.gru(emb, init_hidden, rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.bias_ih_l0, rnn.bias_hh_l0)
@@ -112,7 +112,7 @@ class VAEPieceDecoder(nn.Module):
         their cross-entropy against pieces[:, 1:] with <pad> ignored, in one kernel on the
         time-major logits.  Returns (loss, counts int32 [non-pad tokens, correct argmax])."""
         logits = self.piece_logits(z_vecs, pieces, piece_table, time_major=True, pad_vocab=True)
-        gold = pieces[:, 1:].t().contiguous().to(torch.int32)
+        gold = pieces[:, 1:].t().to(torch.int32).contiguous()
         return ops.token_ce(logits, gold, self.piece_loss.ignore_index, n_classes=self.to_vocab.out_features)
 
     def link_logits(self, node_embedding, z_vecs, pairs, golden=None):

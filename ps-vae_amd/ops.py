@@ -598,11 +598,8 @@ class _BlockTable(Function):
     def forward(ctx, ea, ep, eq):
         (na, da), (npc, dp), (nq, dq) = ea.shape, ep.shape, eq.shape
         D = da + dp + dq
-        Z = ea.new_zeros(na + npc + nq, D + 4)
-        Z[:na, :da] = ea
-        Z[na:na + npc, da:da + dp] = ep
-        Z[na + npc:, da + dp:D] = eq
-        Z[:na, D] = 1.0
+        Z = torch.empty(na + npc + nq, D + 4, dtype=torch.float32, device=ea.device)
+        hip.block_table(ea.contiguous(), ep.contiguous(), eq.contiguous(), Z)   # one launch: blocks, zeros, ones column
         ctx.dims = (na, da, npc, dp, D)
         return Z
 
@@ -882,11 +879,12 @@ class _LinkCe(Function):
             g_hid = torch.empty(P, F, dtype=torch.float32, device=w.device)
             hip.link_ce_bwd_input(dlogits, w, g_loss, g_hid)
         want_gb = ctx.has_bias and ctx.needs_input_grad[2]
+        alloc = torch.empty if P else torch.zeros   # (both are written in full when there is a pair at all)
         if want_gb:
-            gb = torch.zeros(C, dtype=torch.float32, device=w.device)
+            gb = alloc(C, dtype=torch.float32, device=w.device)
         if ctx.needs_input_grad[1]:
             # (dW)^T = hid^T dlogits: F rows fill the 128-row panels, the few classes are columns
-            gwt = torch.zeros(F, C, dtype=torch.float32, device=w.device)
+            gwt = alloc(F, C, dtype=torch.float32, device=w.device)
             if P:
                 hip.gemm(F, C, P, hid2, 1, _ld(hid2), dlogits, C, 1, gwt, C, split_k=0)
             gw = gwt.t() * g_loss
@@ -902,6 +900,54 @@ def link_ce(hid, weight, bias, golden, live=None):
     Returns (loss, logits [P,C], n_correct).  live (device int32 [1]): only the first live[0] rows are
     pairs, the rest pads a fixed-size buffer and takes no part."""
     return _LinkCe.apply(hid, weight, bias, golden, live)
+
+
+# ------------------------------------------------------------------------ the scalar tail of the step
+class _MseSelected(Function):
+    @staticmethod
+    def forward(ctx, pred, props, sel):
+        pred2 = pred if (pred.dtype == torch.float32 and pred.stride(-1) == 1) else pred.float().contiguous()
+        props2 = props if (props.dtype == torch.float32 and props.stride(-1) == 1) else props.float().contiguous()
+        diff = torch.empty(pred2.numel(), dtype=torch.float32, device=pred2.device)
+        loss = torch.empty((), dtype=torch.float32, device=pred2.device)
+        hip.mse_selected_fwd(pred2, props2, sel, diff, loss)
+        ctx.save_for_backward(diff)
+        ctx.shape = pred.shape
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        diff, = ctx.saved_tensors
+        g_pred = torch.empty_like(diff)
+        hip.mse_selected_bwd(diff, g.contiguous().float(), g_pred)
+        return g_pred.view(ctx.shape), None, None
+
+
+def mse_selected(pred, props, sel):
+    """nn.MSELoss()(pred, props[:, sel]) (src/pl_models/ps_vae_model.py:55-57) in one launch each way.
+    pred [B,k], props [B,*] f32, sel int64 [k] on the device."""
+    return _MseSelected.apply(pred, props, sel)
+
+
+class _LossMix(Function):
+    @staticmethod
+    def forward(ctx, rec, pred, kl, alpha, beta):
+        out = torch.empty((), dtype=torch.float32, device=rec.device)
+        hip.loss_mix_fwd(rec.float(), pred.float(), kl.float(), alpha, beta, out)
+        ctx.alpha, ctx.beta = alpha, beta
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g3 = torch.empty(3, dtype=torch.float32, device=g.device)
+        hip.loss_mix_bwd(g.contiguous().float(), ctx.alpha, ctx.beta, g3)
+        return g3[0], g3[1], g3[2], None, None
+
+
+def loss_mix(rec, pred, kl, alpha, beta):
+    """alpha rec + (1 - alpha) pred + beta kl on device scalars (src/pl_models/ps_vae_model.py:71-74), one launch
+    each way; beta: a Python number or a device scalar (no gradient flows to it)."""
+    return _LossMix.apply(rec, pred, kl, alpha, beta)
 
 
 # ------------------------------------------------------------------------ token loss with an ignored label

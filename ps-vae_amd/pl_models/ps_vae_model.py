@@ -13,6 +13,7 @@ import time
 import torch
 import torch.nn as nn
 
+from .. import ops
 from ..data.bpe_dataset import BPEMolDataset, get_dataloader
 from ..modules.encoder import Encoder
 from ..modules.predictor import Predictor
@@ -123,8 +124,11 @@ class PSVAEModel(nn.Module):
                                   return_accu=return_accu, eps=eps)
             props = batch['props']
         pred_prop = self.predictor(z)
-        golden = props.reshape(batch_size, -1).index_select(1, self._selected_props(props.device)).float()
-        pred_loss = self.pred_loss(pred_prop, golden)
+        if pred_prop.is_cuda and type(self.pred_loss) is nn.MSELoss and self.pred_loss.reduction == 'mean':
+            pred_loss = ops.mse_selected(pred_prop, props.reshape(batch_size, -1), self._selected_props(props.device))
+        else:
+            golden = props.reshape(batch_size, -1).index_select(1, self._selected_props(props.device)).float()
+            pred_loss = self.pred_loss(pred_prop, golden)
         return pred_loss, res
 
     def _selected_props(self, device):
@@ -149,6 +153,8 @@ class PSVAEModel(nn.Module):
     def weighted_loss(self, pred_loss, rec_loss, kl_loss):
         alpha = self.config['alpha']
         beta = self.cal_beta() if self.beta_tensor is None else self.beta_tensor
+        if all(torch.is_tensor(v) and v.is_cuda and v.dim() == 0 for v in (pred_loss, rec_loss, kl_loss)):
+            return ops.loss_mix(rec_loss, pred_loss, kl_loss, alpha, beta)      # one launch each way instead of five
         return alpha * rec_loss + (1 - alpha) * pred_loss + beta * kl_loss
 
     def training_step(self, batch, batch_idx):

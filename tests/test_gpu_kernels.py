@@ -683,6 +683,63 @@ def test_rsample_kl_fwd_bwd():
     close(pd.grad, pre.grad, what='d/dlogvar')
 
 
+def test_block_table_against_the_slice_assignments():
+    """_BlockTable (one launch) against the block matrix written slice by slice, and its gradient views."""
+    from ps_vae_amd import ops
+    d = dev()
+    torch.manual_seed(5)
+    ea = torch.randn(11, 50, device=d, requires_grad=True)
+    ep = torch.randn(302, 100, device=d, requires_grad=True)
+    eq = torch.randn(50, 50, device=d, requires_grad=True)
+    Z = ops._BlockTable.apply(ea, ep, eq)
+    want = torch.zeros(363, 204, device=d)
+    want[:11, :50], want[11:313, 50:150], want[313:, 150:200] = ea.detach(), ep.detach(), eq.detach()
+    want[:11, 200] = 1.0
+    assert torch.equal(Z, want)
+    g = torch.randn_like(Z)
+    Z.backward(g)
+    assert torch.equal(ea.grad, g[:11, :50]) and torch.equal(ep.grad, g[11:313, 50:150]) and torch.equal(eq.grad, g[313:, 150:200])
+
+
+@pytest.mark.parametrize('B,sel', [(32, [0, 2]), (4096, [0, 1, 2]), (1, [1])])
+def test_mse_selected_against_mse_loss(B, sel):
+    """ops.mse_selected against nn.MSELoss on the selected property columns (src/pl_models/ps_vae_model.py:55-57)."""
+    from ps_vae_amd import ops
+    d = dev()
+    torch.manual_seed(B)
+    pred = torch.randn(B, len(sel), device=d, requires_grad=True)
+    props = torch.randn(B, 3, device=d)
+    idx = torch.tensor(sel, dtype=torch.int64, device=d)
+    loss = ops.mse_selected(pred, props, idx)
+    (loss * 0.7).backward()
+    ref = pred.detach().double().clone().requires_grad_(True)
+    want = torch.nn.functional.mse_loss(ref, props.double().index_select(1, idx))
+    (want * 0.7).backward()
+    close(loss, want.float(), what='mse')
+    close(pred.grad, ref.grad.float(), what='d/dpred')
+
+
+@pytest.mark.parametrize('beta_on_device', [False, True])
+def test_loss_mix_rounds_as_the_expression(beta_on_device):
+    """ops.loss_mix against alpha * rec + (1 - alpha) * pred + beta * kl (src/pl_models/ps_vae_model.py:71-74):
+    the same bits (every product and sum is rounded on its own in both) and the same three gradients."""
+    from ps_vae_amd import ops
+    d = dev()
+    torch.manual_seed(9)
+    alpha, beta = 0.1, 0.0003
+    for _ in range(20):
+        leaves = [torch.rand((), device=d).mul_(5).requires_grad_(True) for _ in range(3)]
+        twins = [v.detach().clone().requires_grad_(True) for v in leaves]
+        b = torch.tensor(beta, device=d) if beta_on_device else beta
+        got = ops.loss_mix(leaves[0], leaves[1], leaves[2], alpha, b)
+        want = alpha * twins[0] + (1 - alpha) * twins[1] + b * twins[2]
+        assert torch.equal(got, want.detach())
+        (got * 3.0).backward()
+        (want * 3.0).backward()
+        for v, w in zip(leaves, twins):
+            assert torch.equal(v.grad, w.grad)
+
+
 @pytest.mark.parametrize('C,J,K,bias', [(4, 656, 328, True), (3, 70, 33, True), (8, 40, 100, False)])
 def test_affine_merge(C, J, K, bias):
     """W_last (W_out x + b_out) + b_last as one affine map, and the gradients of both layers."""
