@@ -455,12 +455,26 @@ __global__ __launch_bounds__(1024) void affine_merge_fwd_kernel(int C, int J, in
     float acc[MAXC];
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) acc[c] = 0.f;
+    // (eight rows are requested before the first is used: a thread's ~20 rows are a chain of memory round trips
+    // otherwise; the terms are added in the same order either way)
+    constexpr int U = 8;
     if (k <= K)
-        for (int j = jg; j < J; j += 32) {
-            const float w = k < K ? w_out[(long long)j * K + k] : (b_out ? b_out[j] : 0.f);
+        for (int j0 = jg; j0 < J; j0 += 32 * U) {
+            float w[U], wl[U][MAXC];
 #pragma unroll
-            for (int c = 0; c < MAXC; ++c)
-                if (c < C) acc[c] += w_last[c * J + j] * w;
+            for (int u = 0; u < U; ++u) {
+                const int j = j0 + 32 * u, jc = j < J ? j : jg;
+                w[u] = k < K ? w_out[(long long)jc * K + k] : (b_out ? b_out[jc] : 0.f);
+#pragma unroll
+                for (int c = 0; c < MAXC; ++c) wl[u][c] = c < C ? w_last[c * J + jc] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (j0 + 32 * u < J) {
+#pragma unroll
+                    for (int c = 0; c < MAXC; ++c)
+                        if (c < C) acc[c] += wl[u][c] * w[u];
+                }
         }
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) sh[jg][c][kq] = acc[c];

@@ -45,10 +45,9 @@ class GraphedTrainStep:
         self.static = StaticBatch(self.shapes, self.device, tok.chem_vocab.num_bond_type())
         self.pads = dict(atom_pad=tok.atom_pad_idx(), piece_pad=tok.pad_idx())
         self.generator = generator
-        self.beta = torch.zeros((), dtype=torch.float32, device=self.device)
-        self.scalars = torch.zeros(2, dtype=torch.float32, device=self.device)
         self._host = PinnedRing((3,), torch.float32)                       # beta, step size, sqrt(1 - beta2^t)
-        self._staging = torch.zeros(3, dtype=torch.float32, device=self.device)
+        self._step_values = torch.zeros(3, dtype=torch.float32, device=self.device)   # one copy per step fills all three
+        self.beta, self.scalars = self._step_values[0], self._step_values[1:]
         self.graph, self.loss = None, None
         self.warmup_left = max(1, warmup)   # at least one ordinary step: lazy set-up (cached index tensors, workspaces) cannot be recorded
         self.replays = self.fallbacks = 0
@@ -59,10 +58,8 @@ class GraphedTrainStep:
         step_size, bc2_sqrt = hip.adam_step_scalars(self.opt.steps + 1, group['lr'], group['betas'])
         host = self._host.next()
         host[0], host[1], host[2] = float(self.model.cal_beta()), step_size, bc2_sqrt
-        self._staging.copy_(host, non_blocking=True)
+        self._step_values.copy_(host, non_blocking=True)
         self._host.sent()
-        self.beta.copy_(self._staging[0])
-        self.scalars.copy_(self._staging[1:])
 
     def _body(self, batch):
         """Forward, backward and the optimiser's kernels on `batch`, all step-dependent numbers taken
