@@ -369,6 +369,39 @@ def test_gemm_tall_k_repeats_bit_for_bit():
     assert not bad, f'repeats {bad} differ from the first result'
 
 
+@pytest.mark.parametrize('rows,K', [(290, 300), (749, 300), (290, 1160), (33, 56)])
+def test_gemm_small_batch_products_repeat_bit_for_bit(rows, K):
+    """The three products of a Linear at the sizes of a batch of 32 (the latency form of the kernel: 32 x 32 tiles
+    whose four waves split K, k-tiles requested five ahead through two LDS stages with one barrier per tile,
+    partial tiles summed through LDS) against float64 and thirty times in a row: a tile read before it was
+    written, or partial sums added in a varying order, would change low bits that the float64 comparison cannot see."""
+    from ps_vae_amd import hip
+    d = dev()
+    g = torch.Generator(device=d).manual_seed(rows + K)
+    N = 300
+    x = torch.randn(rows, K, device=d, generator=g)
+    w = torch.randn(N, K, device=d, generator=g) * 0.05
+    b = torch.randn(N, device=d, generator=g)
+    gy = torch.randn(rows, N, device=d, generator=g)
+
+    def run():
+        y, gx, gw, gb = (torch.empty(rows, N, device=d), torch.empty(rows, K, device=d), torch.empty(N, K, device=d),
+                         torch.empty(N, device=d))
+        hip.gemm(rows, N, K, x, K, 1, w, 1, K, y, N, bias=b, relu=True)
+        hip.gemm(rows, K, N, gy, N, 1, w, K, 1, gx, K)
+        hip.gemm(N, K, rows, gy, 1, N, x, K, 1, gw, K, split_k=0, rowsum=gb)
+        return y, gx, gw, gb
+
+    first = run()
+    close(first[0], torch.relu(x.double() @ w.double().t() + b.double()), what='y')
+    close(first[1], gy.double() @ w.double(), what='dx')
+    close(first[2], gy.double().t() @ x.double(), what='dw')
+    close(first[3], gy.double().sum(0), what='db')
+    for i in range(30):
+        again = run()
+        assert all(torch.equal(a, f) for a, f in zip(again, first)), f'repeat {i} differs from the first result'
+
+
 def test_gemm_large_split_k():
     from ps_vae_amd import hip
     d = dev()
