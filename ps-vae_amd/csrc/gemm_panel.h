@@ -243,10 +243,12 @@ __global__ __launch_bounds__(THREADS, KG > 1 ? 1 : ((MASK || WN > 1 || TN > 5) ?
         constexpr int D = 5, KSTEPS = BK / KG;
         float4 fa[D][PA], fb[D][PB], fm[D][MASK ? PA : 1], none[1];
         const int n_tiles = (k_end - k_begin + BK - 1) / BK;
+        if (k_begin < k_end) {   // (block-uniform; an empty K range may come with null operands)
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            LA::template load<MASK>(fa[d], fm[d], g.A, g.amask, g.sa_m, g.sa_k, m0, k_begin + d * BK, g.M, k_end, tid);
-            LB::template load<false>(fb[d], none, g.B, nullptr, g.sb_n, g.sb_k, n0, k_begin + d * BK, n_lim, k_end, tid);
+            for (int d = 0; d < D; ++d) {
+                LA::template load<MASK>(fa[d], fm[d], g.A, g.amask, g.sa_m, g.sa_k, m0, k_begin + d * BK, g.M, k_end, tid);
+                LB::template load<false>(fb[d], none, g.B, nullptr, g.sb_n, g.sb_k, n0, k_begin + d * BK, n_lim, k_end, tid);
+            }
         }
         const float *a_rd = As + (lhi + grp * KSTEPS) * LA::STRIDE + l31;
         const float *b_rd = Bs + (lhi + grp * KSTEPS) * LB::STRIDE + l31;

@@ -402,6 +402,19 @@ def test_gemm_small_batch_products_repeat_bit_for_bit(rows, K):
         assert all(torch.equal(a, f) for a, f in zip(again, first)), f'repeat {i} differs from the first result'
 
 
+@pytest.mark.parametrize('rows', [40, 4000, 50000])
+def test_gemm_with_an_empty_contraction(rows):
+    """K = 0 (operands without storage): the result is act(bias) in every kernel the row count selects."""
+    from ps_vae_amd import hip
+    d = dev()
+    N = 300
+    x, w = torch.empty(rows, 0, device=d), torch.empty(N, 0, device=d)
+    b = torch.randn(N, device=d)
+    y = torch.full((rows, N), float('nan'), device=d)
+    hip.gemm(rows, N, 0, x, 0, 1, w, 1, 0, y, N, bias=b, relu=True)
+    assert torch.equal(y, torch.relu(b).expand(rows, N))
+
+
 def test_gemm_large_split_k():
     from ps_vae_amd import hip
     d = dev()
