@@ -501,7 +501,13 @@ KEY_CHUNK = 256   # entries per work unit of the keyed row sum
 KEY_SORT_MAX_ROWS = 8192   # table rows psvae_key_sort accepts (all tables together)
 
 
-def key_sort(keys, sizes, chunk=KEY_CHUNK):
+def key_chunk(entries):
+    """Entries per work unit for id vectors of `entries` rows: small units for a small batch, whose sums would
+    otherwise sit on a handful of CUs (a CU receives a fixed share of the memory bandwidth, see gemm_panel.h)."""
+    return 32 if entries <= 8192 else KEY_CHUNK
+
+
+def key_sort(keys, sizes, chunk=None):
     """psvae_key_sort: keys = 1..3 int32 id vectors over the same V entries, sizes = rows of their
     tables.  Returns (perm [len(keys) * V], row_off [R + 1], unit_off [R + 1]) int32."""
     V, dev = keys[0].numel(), keys[0].device
@@ -512,14 +518,15 @@ def key_sort(keys, sizes, chunk=KEY_CHUNK):
     k = list(keys) + [None] * (3 - len(keys))
     n = [int(s) for s in sizes] + [0] * (3 - len(sizes))
     _count()
-    ops().key_sort(k[0], k[1], k[2], n[0], n[1], n[2], chunk, perm, row_off, unit_off)
+    ops().key_sort(k[0], k[1], k[2], n[0], n[1], n[2], key_chunk(V) if chunk is None else chunk, perm, row_off, unit_off)
     return perm, row_off, unit_off
 
 
-def keyed_row_sum(g, perm, row_off, unit_off, out, chunk=KEY_CHUNK):
-    """out[r] = sum of g[perm[i]] over i in [row_off[r], row_off[r+1]) (psvae_keyed_row_sum)."""
+def keyed_row_sum(g, perm, row_off, unit_off, out, chunk=None):
+    """out[r] = sum of g[perm[i]] over i in [row_off[r], row_off[r+1]) (psvae_keyed_row_sum).  chunk: the one the
+    sort was made with (None on both sides: key_chunk of the row count of g, which is the length of the id vectors)."""
     _count()
-    ops().keyed_row_sum(g, perm, row_off, unit_off, chunk, out)
+    ops().keyed_row_sum(g, perm, row_off, unit_off, key_chunk(g.shape[0]) if chunk is None else chunk, out)
 
 
 def embed_trans_fwd(x, xp, xq, sizes, T, out):

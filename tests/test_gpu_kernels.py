@@ -874,7 +874,7 @@ def test_key_sort_and_keyed_row_sum(V, sizes, H):
         if t == 0 and V > 10:
             k[rng.random(V) < 0.7] = min(1, n - 1)          # one dominant id, like carbon among the atom types
         keys.append(k.astype(np.int32))
-    chunk = hip.KEY_CHUNK
+    chunk = hip.key_chunk(V)
     perm, row_off, unit_off = hip.key_sort([torch.from_numpy(k).to(d) for k in keys], sizes)
     R = sum(sizes)
     want_perm, counts = [], []

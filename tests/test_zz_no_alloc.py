@@ -3,6 +3,7 @@ partials live in a fixed device array inside the library) against psvae_gine_agg
 the same inputs, through the C-ABI, bit for bit: two calls in a row, the second on a smaller
 input (stale partials of the first call must not leak into it), then the size limit."""
 import ctypes
+import gc
 
 import numpy as np
 import pytest
@@ -42,10 +43,18 @@ def test_noalloc_backward_equals_workspace_backward_twice_then_smaller():
         got_gt = torch.full_like(table, 0.25)
         hip.gine_aggregate_bwd(x, table, gy, csr.t_row_ptr, csr.t_col, csr.t_cls, want_gx, want_gt, add=add,
                                accumulate_table=accumulate)
-        before = torch.cuda.memory_allocated(dev)
-        hip.gine_aggregate_bwd_noalloc(x, table, gy, csr.t_row_ptr, csr.t_col, csr.t_cls, got_gx, got_gt, add=add,
-                                       accumulate_table=accumulate)
-        assert torch.cuda.memory_allocated(dev) == before
+        # (garbage of earlier tests - autograd nodes in reference cycles that still hold device tensors - must not
+        # be collected between the two readings: collect it now and keep the collector off in between)
+        gc.collect()
+        torch.cuda.synchronize()
+        gc.disable()
+        try:
+            before = torch.cuda.memory_allocated(dev)
+            hip.gine_aggregate_bwd_noalloc(x, table, gy, csr.t_row_ptr, csr.t_col, csr.t_cls, got_gx, got_gt, add=add,
+                                           accumulate_table=accumulate)
+            assert torch.cuda.memory_allocated(dev) == before
+        finally:
+            gc.enable()
         torch.cuda.synchronize()
         assert torch.equal(got_gx, want_gx), (V, H, C)
         assert torch.equal(got_gt, want_gt), (V, H, C)
