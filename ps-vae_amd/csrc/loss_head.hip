@@ -28,22 +28,31 @@ __global__ __launch_bounds__(256) void block_table_kernel(int na, int da, int np
 
 // mean over B x k of (pred[b][j] - props[b][sel[j]])^2; the differences are kept for the backward.
 // One workgroup, partial sums in a fixed order.
-__global__ __launch_bounds__(256) void mse_selected_fwd_kernel(int B, int k, const float *__restrict__ pred, int ldp,
+__global__ __launch_bounds__(1024) void mse_selected_fwd_kernel(int B, int k, const float *__restrict__ pred, int ldp,
                                                                const float *__restrict__ props, int ldr,
                                                                const long long *__restrict__ sel, float *__restrict__ diff,
                                                                float *__restrict__ loss) {
-    __shared__ float part[256];
+    __shared__ float part[1024];
     const int n = B * k;
     float s = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const int b = i / k, j = i % k;
-        const float d = pred[(long long)b * ldp + j] - props[(long long)b * ldr + (int)sel[j]];
-        diff[i] = d;
-        s += d * d;
+    for (int i0 = threadIdx.x; i0 < n; i0 += 1024 * 8) {   // eight entries requested before the first is used
+        float a[8], r[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = min(i0 + 1024 * u, n - 1), b = i / k, j = i % k;
+            a[u] = pred[(long long)b * ldp + j], r[u] = props[(long long)b * ldr + (int)sel[j]];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (i0 + 1024 * u < n) {
+                const float d = a[u] - r[u];
+                diff[i0 + 1024 * u] = d;
+                s += d * d;
+            }
     }
     part[threadIdx.x] = s;
     __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
+    for (int w = 512; w > 0; w >>= 1) {
         if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
         __syncthreads();
     }
@@ -92,7 +101,7 @@ extern "C" int psvae_mse_selected_fwd(int B, int k, const float *pred, int ld_pr
     PSVAE_REQUIRE(B > 0 && k > 0, PSVAE_EINVAL, "psvae_mse_selected_fwd: empty input (B=%d k=%d)", B, k);
     PSVAE_REQUIRE((long long)B * k <= (1 << 24), PSVAE_ETOOLARGE, "psvae_mse_selected_fwd: more than 2^24 entries");
     PSVAE_REQUIRE(pred && props && sel && diff && loss && ld_pred >= k, PSVAE_EINVAL, "psvae_mse_selected_fwd: null pointer or bad stride");
-    hipLaunchKernelGGL(mse_selected_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, B, k, pred, ld_pred, props, ld_props,
+    hipLaunchKernelGGL(mse_selected_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, B, k, pred, ld_pred, props, ld_props,
                        (const long long *)sel, diff, loss);
     PSVAE_CHECK_LAUNCH("psvae_mse_selected_fwd");
     return PSVAE_OK;

@@ -122,13 +122,13 @@ __global__ void segment_sum_fwd_kernel(int cols, const float4 *__restrict__ x, i
     const int r0 = seg_begin[b], r1 = seg_end[b];
     for (int c = threadIdx.x; c < cols; c += blockDim.x) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        // four rows requested at once (indices clamped, contributions predicated, summed in row order)
-        for (int r = r0; r < r1; r += 4) {
-            float4 v[4];
+        // eight rows requested at once (indices clamped, contributions predicated, summed in row order)
+        for (int r = r0; r < r1; r += 8) {
+            float4 v[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = x[(long long)min(r + u, r1 - 1) * ldx4 + c];
+            for (int u = 0; u < 8; ++u) v[u] = x[(long long)min(r + u, r1 - 1) * ldx4 + c];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < 8; ++u)
                 if (r + u < r1) acc = add4(acc, v[u]);
         }
         out[(long long)b * ldo4 + c] = acc;
@@ -633,6 +633,97 @@ __global__ __launch_bounds__(256) void link_ce_fwd_kernel(int P, int F, int C, c
     }
 }
 
+// The same with half a wave per pair (rows of at most 32 * ITER float4): the whole row is requested at once, two
+// rows are in flight per wave, and the lane sums and the softmax tail run for both at the same time.
+template <int MAXC, int ITER>
+__global__ __launch_bounds__(256) void link_ce_fwd_half_kernel(int P, int F, int C, const float *__restrict__ hid,
+                                                               int ldhid, const float *__restrict__ W,
+                                                               const float *__restrict__ bias,
+                                                               const int32_t *__restrict__ golden,
+                                                               float *__restrict__ logits, float *__restrict__ dlogits,
+                                                               float *__restrict__ part_loss, int *__restrict__ part_ok,
+                                                               const int32_t *__restrict__ live) {
+    extern __shared__ __align__(16) float sW[];
+    __shared__ float sh_loss[8];
+    __shared__ int sh_ok[8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, l = lane & 31;
+    for (int i = threadIdx.x; i < C * F; i += 256) sW[i] = W[i];
+    __syncthreads();
+    float loss_acc = 0.f;
+    int ok_acc = 0;
+    const int P_live = live ? min(P, max(*live, 0)) : P;
+    const int F4 = F >> 2;
+    for (int p0 = (blockIdx.x * 4 + wave) * 2; p0 < P; p0 += gridDim.x * 8) {
+        const int p = p0 + half;
+        const bool in = p < P, live_row = p < P_live;
+        const float4 *row4 = reinterpret_cast<const float4 *>(hid + (long long)(live_row ? p : 0) * ldhid);
+        float4 hv[ITER];
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int f = l + 32 * it;
+            hv[it] = row4[f < F4 ? f : 0];
+        }
+        float dot[MAXC];
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) dot[c] = 0.f;
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int f = l + 32 * it;
+            if (f < F4 && live_row) {
+#pragma unroll
+                for (int c = 0; c < MAXC; ++c)
+                    if (c < C) {
+                        const float4 wv = reinterpret_cast<const float4 *>(sW)[c * F4 + f];
+                        dot[c] += (hv[it].x * wv.x + hv[it].y * wv.y) + (hv[it].z * wv.z + hv[it].w * wv.w);
+                    }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+#pragma unroll
+            for (int d = 16; d > 0; d >>= 1) dot[c] += __shfl_xor(dot[c], d);   // (stays inside the half)
+        if (l == 0 && in) {
+            if (!live_row) {   // padding behind the live count: zero logits and gradient, no part in the mean
+                for (int c = 0; c < C; ++c) logits[(long long)p * C + c] = 0.f, dlogits[(long long)p * C + c] = 0.f;
+            } else {
+                float mx = -INFINITY;
+                int arg = 0;
+#pragma unroll
+                for (int c = 0; c < MAXC; ++c)
+                    if (c < C) {
+                        dot[c] += bias ? bias[c] : 0.f;
+                        if (dot[c] > mx) mx = dot[c], arg = c;
+                    }
+                float se = 0.f;
+#pragma unroll
+                for (int c = 0; c < MAXC; ++c)
+                    if (c < C) se += expf(dot[c] - mx);
+                const float lse = mx + logf(se);
+                const int gold = golden[p];
+                float lg = 0.f;
+#pragma unroll
+                for (int c = 0; c < MAXC; ++c)
+                    if (c < C) {
+                        if (c == gold) lg = dot[c];
+                        logits[(long long)p * C + c] = dot[c];
+                        dlogits[(long long)p * C + c] = (expf(dot[c] - lse) - (c == gold ? 1.f : 0.f)) / (float)P_live;
+                    }
+                loss_acc += lse - lg;
+                ok_acc += (arg == gold);
+            }
+        }
+    }
+    if (l == 0) sh_loss[wave * 2 + half] = loss_acc, sh_ok[wave * 2 + half] = ok_acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = sh_loss[0];
+        int k = sh_ok[0];
+        for (int i = 1; i < 8; ++i) t += sh_loss[i], k += sh_ok[i];
+        part_loss[blockIdx.x] = t;
+        part_ok[blockIdx.x] = k;
+    }
+}
+
 __global__ void link_ce_finish_kernel(int P, int n_part, const float *__restrict__ part_loss,
                                       const int *__restrict__ part_ok, float *__restrict__ loss,
                                       int32_t *__restrict__ n_correct, const int32_t *__restrict__ live) {
@@ -665,6 +756,27 @@ __global__ void link_ce_bwd_input_kernel(int P, int F, int C, const float *__res
         float s = 0.f;
         for (int c = 0; c < C; ++c) s += dlogits[(long long)p * C + c] * W[c * F + f];
         g_hid[(long long)p * ldg + f] = gl * s;
+    }
+}
+
+// float4 columns: thread = (pair, 4 columns), consecutive threads along the row (16-byte stores, 32-bit index math)
+template <int MAXC>
+__global__ __launch_bounds__(256) void link_ce_bwd_input_vec_kernel(int P, int F4, int C, const float *__restrict__ dlogits,
+                                                                    const float4 *__restrict__ W4, const float *__restrict__ g_loss,
+                                                                    float4 *__restrict__ g_hid4, int ldg4) {
+    const float gl = *g_loss;
+    const unsigned total = (unsigned)P * (unsigned)F4;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const unsigned p = i / (unsigned)F4, f = i - p * (unsigned)F4;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+            if (c < C) {
+                const float d = dlogits[(long long)p * C + c];
+                const float4 w = W4[c * F4 + f];
+                s.x += d * w.x, s.y += d * w.y, s.z += d * w.z, s.w += d * w.w;
+            }
+        g_hid4[(long long)p * ldg4 + f] = make_float4(gl * s.x, gl * s.y, gl * s.z, gl * s.w);
     }
 }
 
@@ -725,9 +837,9 @@ int colsum_rows_per_block(int M) {
     return r < 32 ? 32 : r;
 }
 
-constexpr int LINK_CE_MAX_BLOCKS = 1024;
+constexpr int LINK_CE_MAX_BLOCKS = 2048;
 int link_ce_blocks(int P) {
-    int b = psvae_cdiv(P, 4);
+    int b = psvae_cdiv(P, 8);   // (two pairs per wave at a time)
     return b < 1 ? 1 : (b > LINK_CE_MAX_BLOCKS ? LINK_CE_MAX_BLOCKS : b);
 }
 
@@ -816,7 +928,8 @@ extern "C" int psvae_segment_sum_fwd(int B, int W, const float *x, int ldx, cons
                                      const int32_t *seg_end, float *out, int ldo, void *stream) {
     int rc = check_seg("psvae_segment_sum_fwd", B, W, x, ldx, out, ldo, seg_begin, seg_end);
     if (rc || B == 0) return rc;
-    const int cols = W / 4, threads = cols >= 256 ? 256 : psvae_cdiv(cols, 64) * 64;
+    // (every column in one pass where 1024 threads cover the row: 300 float4 columns on 320 threads, not 256 + 44)
+    const int cols = W / 4, threads = cols >= 1024 ? 1024 : psvae_cdiv(cols, 64) * 64;
     hipLaunchKernelGGL(segment_sum_fwd_kernel, dim3(B), dim3(threads), 0, (hipStream_t)stream, cols,
                        (const float4 *)x, ldx / 4, seg_begin, seg_end, (float4 *)out, ldo / 4);
     PSVAE_CHECK_LAUNCH("psvae_segment_sum_fwd");
@@ -1055,7 +1168,18 @@ extern "C" int psvae_link_ce_fwd(int P, int F, int C, const float *hid, int ldhi
 #define PSVAE_LINK_CE(MAXC, VEC, LDSW)                                                                            \
     hipLaunchKernelGGL((link_ce_fwd_kernel<MAXC, VEC, LDSW>), dim3(blocks), dim3(256), shm, s, P, F, C, hid, ldhid, \
                        W, b, golden, logits, dlogits, part_loss, part_ok, live_count)
-    if (C <= 4) {
+    const int iters = psvae_cdiv(F / 4, 32);
+    if (vec && ldsw && iters <= 4) {   // half a wave per pair
+#define PSVAE_LINK_CE_HALF(MAXC, ITER)                                                                                  \
+    hipLaunchKernelGGL((link_ce_fwd_half_kernel<MAXC, ITER>), dim3(blocks), dim3(256), shm, s, P, F, C, hid, ldhid, W, b, \
+                       golden, logits, dlogits, part_loss, part_ok, live_count)
+        if (C <= 4) {
+            if (iters <= 2) PSVAE_LINK_CE_HALF(4, 2); else if (iters == 3) PSVAE_LINK_CE_HALF(4, 3); else PSVAE_LINK_CE_HALF(4, 4);
+        } else {
+            if (iters <= 2) PSVAE_LINK_CE_HALF(8, 2); else if (iters == 3) PSVAE_LINK_CE_HALF(8, 3); else PSVAE_LINK_CE_HALF(8, 4);
+        }
+#undef PSVAE_LINK_CE_HALF
+    } else if (C <= 4) {
         if (vec && ldsw) PSVAE_LINK_CE(4, true, true);
         else if (ldsw) PSVAE_LINK_CE(4, false, true);
         else PSVAE_LINK_CE(4, false, false);
@@ -1077,8 +1201,19 @@ extern "C" int psvae_link_ce_bwd_input(int P, int F, int C, const float *dlogits
     PSVAE_REQUIRE(P >= 0 && F > 0 && C > 0 && ldg >= F, PSVAE_EINVAL, "psvae_link_ce_bwd_input: bad sizes");
     if (P == 0) return PSVAE_OK;
     PSVAE_REQUIRE(dlogits && W && g_loss && g_hid, PSVAE_EINVAL, "psvae_link_ce_bwd_input: null pointer");
-    hipLaunchKernelGGL(link_ce_bwd_input_kernel, dim3(grid_for((long long)P * F, 256, 8192)), dim3(256), 0,
-                       (hipStream_t)stream, P, F, C, dlogits, W, g_loss, g_hid, ldg);
+    if (F % 4 == 0 && ldg % 4 == 0 && C <= 8 && (uintptr_t)W % 16 == 0 && (uintptr_t)g_hid % 16 == 0 &&
+        (long long)P * (F / 4) < (1ll << 32)) {
+        const dim3 grid(grid_for((long long)P * (F / 4), 256, 16384));
+        if (C <= 4)
+            hipLaunchKernelGGL(link_ce_bwd_input_vec_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, P, F / 4, C, dlogits,
+                               (const float4 *)W, g_loss, (float4 *)g_hid, ldg / 4);
+        else
+            hipLaunchKernelGGL(link_ce_bwd_input_vec_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, P, F / 4, C, dlogits,
+                               (const float4 *)W, g_loss, (float4 *)g_hid, ldg / 4);
+    } else {
+        hipLaunchKernelGGL(link_ce_bwd_input_kernel, dim3(grid_for((long long)P * F, 256, 8192)), dim3(256), 0,
+                           (hipStream_t)stream, P, F, C, dlogits, W, g_loss, g_hid, ldg);
+    }
     PSVAE_CHECK_LAUNCH("psvae_link_ce_bwd_input");
     return PSVAE_OK;
 }
