@@ -402,6 +402,15 @@ int psvae_pair_gather_bwd(int B, int H, int L, const float *g_feats,
 int psvae_pair_combine_fwd(int P, int F, const float *a, int lda, const float *b, int ldb,
                            const float *c, int ldc, const int32_t *src, const int32_t *dst,
                            const int32_t *graph, int act, float *out, int ldo, void *stream);
+/* The same rows with one workgroup per graph that stages the graph's a / b rows in LDS (pairs of graph g are
+ * pair_ptr[g] .. pair_ptr[g+1], its nodes node_begin[g] .. node_end[g]; src / dst hold global node ids as above and
+ * the graph row of c is g): every node row is read once, which pays when a graph has many more pairs than nodes -
+ * all candidate pairs of generated molecules (src/modules/vae_piece_decoder.py:224-238).  max_nodes sizes the
+ * staging area; a graph with more nodes is served from memory, with the same result. */
+int psvae_pair_combine_fwd_graphs(int B, int F, int max_nodes, const float *a, int lda, const float *b, int ldb,
+                                  const float *c, int ldc, const int32_t *src, const int32_t *dst,
+                                  const int32_t *pair_ptr, const int32_t *node_begin, const int32_t *node_end,
+                                  int act, float *out, int ldo, void *stream);
 /* Its backward for a = ab[:, :F], b = ab[:, F:] (one [V, 2F] matrix, as (h [Wa;Wb]^T) produces it): with
  * m[p] = g_out[p] gated by out[p] > 0 when act is ReLU (`out` = the forward's result),
  * g_ab[v][:F] = sum of m[p] over pairs with src[p] == v, g_ab[v][F:] = the same over dst[p] == v,

@@ -328,6 +328,103 @@ __global__ void pair_combine_fwd_kernel(int P, int f4, const float4 *__restrict_
     }
 }
 
+// The same for rows of at most 256 float4: a thread keeps its column and walks pairs (no index division in the
+// loop), blockDim / f4 pairs per pass and four passes requested before the first is used.
+__global__ __launch_bounds__(256) void pair_combine_fwd_rows_kernel(int P, int f4, const float4 *__restrict__ a, int lda4,
+                                                                    const float4 *__restrict__ b, int ldb4,
+                                                                    const float4 *__restrict__ c, int ldc4,
+                                                                    const int32_t *__restrict__ src, const int32_t *__restrict__ dst,
+                                                                    const int32_t *__restrict__ graph, int relu,
+                                                                    float4 *__restrict__ out, int ldo4) {
+    const int ppb = 256 / f4;
+    const int tp = threadIdx.x / f4, f = threadIdx.x - tp * f4;
+    if (tp >= ppb) return;
+    const long long stride = (long long)gridDim.x * ppb;
+    constexpr int U = 4;
+    for (long long p0 = (long long)blockIdx.x * ppb + tp; p0 < P; p0 += U * stride) {
+        int si[U], di[U], gi[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long p = p0 + u * stride < P ? p0 + u * stride : P - 1;
+            si[u] = src[p], di[u] = dst[p], gi[u] = graph[p];
+        }
+        float4 x[U], y[U], w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            x[u] = a[(long long)si[u] * lda4 + f], y[u] = b[(long long)di[u] * ldb4 + f];
+            w[u] = c[(long long)gi[u] * ldc4 + f];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (p0 + u * stride >= P) break;
+            float4 o = make_float4((x[u].x + y[u].x) + w[u].x, (x[u].y + y[u].y) + w[u].y, (x[u].z + y[u].z) + w[u].z,
+                                   (x[u].w + y[u].w) + w[u].w);
+            if (relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
+            out[(p0 + u * stride) * ldo4 + f] = o;
+        }
+    }
+}
+
+// One workgroup per graph: the a / b rows of the graph's nodes are staged in LDS (a block of cp4 float4 columns
+// at a time) and every pair row is formed from there, so the kernel reads each node row once and is bound by
+// the rows it writes - what counts when a graph has many more pairs than nodes (all candidate pairs of a
+// generated molecule).  A graph with more than max_nodes nodes reads its rows from memory instead.
+__global__ __launch_bounds__(256) void pair_combine_fwd_graph_kernel(int f4, int cp4, int max_nodes, const float4 *__restrict__ a,
+                                                                     int lda4, const float4 *__restrict__ b, int ldb4,
+                                                                     const float4 *__restrict__ c, int ldc4,
+                                                                     const int32_t *__restrict__ src, const int32_t *__restrict__ dst,
+                                                                     const int32_t *__restrict__ pair_ptr,
+                                                                     const int32_t *__restrict__ node_begin,
+                                                                     const int32_t *__restrict__ node_end, int relu,
+                                                                     float4 *__restrict__ out, int ldo4) {
+    extern __shared__ float4 s_rows[];
+    float4 *sA = s_rows, *sB = s_rows + (size_t)max_nodes * cp4;
+    const int g = blockIdx.x;
+    const int n0 = node_begin[g], n = node_end[g] - n0;
+    const int p0 = pair_ptr[g], p1 = pair_ptr[g + 1];
+    if (p0 >= p1) return;   // block-uniform
+    const bool staged = n <= max_nodes;
+    for (int f0 = 0; f0 < f4; f0 += cp4) {
+        const int w = min(cp4, f4 - f0);
+        if (staged) {
+            for (int i = threadIdx.x; i < n * w; i += 256) {
+                const int r = i / w, col = i - r * w;
+                sA[r * cp4 + col] = a[(long long)(n0 + r) * lda4 + f0 + col];
+                sB[r * cp4 + col] = b[(long long)(n0 + r) * ldb4 + f0 + col];
+            }
+        }
+        __syncthreads();
+        const int ppb = 256 / w, tp = threadIdx.x / w, f = threadIdx.x - tp * w;
+        if (tp < ppb) {
+            const float4 z = c[(long long)g * ldc4 + f0 + f];
+            constexpr int U = 4;   // the node ids of four pairs are requested before the first row is formed
+            for (int q = p0 + tp; q < p1; q += U * ppb) {
+                int si[U], di[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int p = min(q + u * ppb, p1 - 1);
+                    si[u] = src[p], di[u] = dst[p];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int p = q + u * ppb;
+                    if (p >= p1) break;
+                    const float4 x = staged ? sA[(si[u] - n0) * cp4 + f] : a[(long long)si[u] * lda4 + f0 + f];
+                    const float4 y = staged ? sB[(di[u] - n0) * cp4 + f] : b[(long long)di[u] * ldb4 + f0 + f];
+                    float4 o = make_float4((x.x + y.x) + z.x, (x.y + y.y) + z.y, (x.z + y.z) + z.z, (x.w + y.w) + z.w);
+                    if (relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
+                    // (streamed: the rows are far more than the caches hold and are read back by a later kernel)
+                    __builtin_nontemporal_store(o.x, &out[(long long)p * ldo4 + f0 + f].x);
+                    __builtin_nontemporal_store(o.y, &out[(long long)p * ldo4 + f0 + f].y);
+                    __builtin_nontemporal_store(o.z, &out[(long long)p * ldo4 + f0 + f].z);
+                    __builtin_nontemporal_store(o.w, &out[(long long)p * ldo4 + f0 + f].w);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // One workgroup per graph.  Pairs of the graph are staged CHUNK at a time in LDS (node ids
 // local to the graph); thread (slot, c) sums column c of the matching feature rows for nodes
 // slot, slot+slots, ...  The order of the sum is the pair order: deterministic.
@@ -1048,9 +1145,45 @@ extern "C" int psvae_pair_combine_fwd(int P, int F, const float *a, int lda, con
                   "%s: operands must be 16-byte aligned", fn);
     PSVAE_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 && ldo % 4 == 0 && lda >= F && ldb >= F && ldc >= F &&
                       ldo >= F, PSVAE_EINVAL, "%s: bad row stride", fn);
-    hipLaunchKernelGGL(pair_combine_fwd_kernel, dim3(grid_for((long long)P * (F / 4), 256, 16384)), dim3(256), 0,
-                       (hipStream_t)stream, P, F / 4, (const float4 *)a, lda / 4, (const float4 *)b, ldb / 4,
-                       (const float4 *)c, ldc / 4, src, dst, graph, act, (float4 *)out, ldo / 4);
+    if (F / 4 <= 256) {
+        const int ppb = 256 / (F / 4);
+        hipLaunchKernelGGL(pair_combine_fwd_rows_kernel, dim3(grid_for(psvae_cdiv(P, 4), ppb, 16384)), dim3(256), 0,
+                           (hipStream_t)stream, P, F / 4, (const float4 *)a, lda / 4, (const float4 *)b, ldb / 4,
+                           (const float4 *)c, ldc / 4, src, dst, graph, act, (float4 *)out, ldo / 4);
+    } else {
+        hipLaunchKernelGGL(pair_combine_fwd_kernel, dim3(grid_for((long long)P * (F / 4), 256, 16384)), dim3(256), 0,
+                           (hipStream_t)stream, P, F / 4, (const float4 *)a, lda / 4, (const float4 *)b, ldb / 4,
+                           (const float4 *)c, ldc / 4, src, dst, graph, act, (float4 *)out, ldo / 4);
+    }
+    PSVAE_CHECK_LAUNCH(fn);
+    return PSVAE_OK;
+}
+
+extern "C" int psvae_pair_combine_fwd_graphs(int B, int F, int max_nodes, const float *a, int lda, const float *b, int ldb,
+                                             const float *c, int ldc, const int32_t *src, const int32_t *dst,
+                                             const int32_t *pair_ptr, const int32_t *node_begin, const int32_t *node_end,
+                                             int act, float *out, int ldo, void *stream) {
+    const char *fn = "psvae_pair_combine_fwd_graphs";
+    PSVAE_REQUIRE(B >= 0 && F > 0 && F % 4 == 0 && F <= 1024 && max_nodes >= 1, PSVAE_EINVAL,
+                  "%s: F=%d must be a multiple of 4 up to 1024, max_nodes=%d at least 1", fn, F, max_nodes);
+    PSVAE_REQUIRE(act == PSVAE_ACT_NONE || act == PSVAE_ACT_RELU, PSVAE_EINVAL, "%s: bad act %d", fn, act);
+    if (B == 0) return PSVAE_OK;
+    PSVAE_REQUIRE(a && b && c && src && dst && pair_ptr && node_begin && node_end && out, PSVAE_EINVAL, "%s: null operand", fn);
+    PSVAE_REQUIRE(psvae_aligned16(a) && psvae_aligned16(b) && psvae_aligned16(c) && psvae_aligned16(out), PSVAE_EINVAL,
+                  "%s: operands must be 16-byte aligned", fn);
+    PSVAE_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 && ldo % 4 == 0 && lda >= F && ldb >= F && ldc >= F &&
+                      ldo >= F, PSVAE_EINVAL, "%s: bad row stride", fn);
+    // column block: both row sets of max_nodes nodes in at most 64 KB of LDS (two workgroups per CU); a graph with
+    // more nodes than the staging area holds is served from memory by the kernel itself
+    const int f4 = F / 4;
+    const int nodes = max_nodes > 2048 ? 2048 : max_nodes;
+    int cp4 = (64 * 1024) / (nodes * 2 * 16);
+    if (cp4 > f4) cp4 = f4;
+    if (cp4 < 1) cp4 = 1;
+    const size_t lds = (size_t)nodes * cp4 * 2 * 16;
+    hipLaunchKernelGGL(pair_combine_fwd_graph_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, f4, cp4, nodes,
+                       (const float4 *)a, lda / 4, (const float4 *)b, ldb / 4, (const float4 *)c, ldc / 4, src, dst, pair_ptr,
+                       node_begin, node_end, act, (float4 *)out, ldo / 4);
     PSVAE_CHECK_LAUNCH(fn);
     return PSVAE_OK;
 }

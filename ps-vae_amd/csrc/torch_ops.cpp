@@ -248,6 +248,21 @@ void pair_combine_fwd(const Tensor &a, const Tensor &b, const Tensor &c, const T
           fn);
 }
 
+void pair_combine_fwd_graphs(const Tensor &a, const Tensor &b, const Tensor &c, const Tensor &src, const Tensor &dst,
+                             const Tensor &pair_ptr, const Tensor &node_begin, const Tensor &node_end, int64_t max_nodes, bool relu,
+                             Tensor out) {
+    PSVAE_ON_DEVICE("psvae::pair_combine_fwd_graphs", p(a), p(b), p(c), p(src), p(dst), p(pair_ptr), p(node_begin), p(node_end), p(out));
+    const char *fn = "psvae_pair_combine_fwd_graphs";
+    const int B = (int)pair_ptr.numel() - 1;
+    TORCH_CHECK(B >= 0 && node_begin.numel() >= B && node_end.numel() >= B && c.size(0) >= B && out.size(0) == src.numel() &&
+                    dst.numel() == src.numel(), fn, ": pair_ptr [B+1], node ranges and graph rows for B graphs, out [pairs, F]");
+    check(psvae_pair_combine_fwd_graphs(B, (int)out.size(1), (int)max_nodes, f32(a, fn), (int)row_stride(a, fn), f32(b, fn),
+                                        (int)row_stride(b, fn), f32(c, fn), (int)row_stride(c, fn), i32(src, fn), i32(dst, fn),
+                                        i32(pair_ptr, fn), i32(node_begin, fn), i32(node_end, fn),
+                                        relu ? PSVAE_ACT_RELU : PSVAE_ACT_NONE, f32_mut(out, fn), (int)row_stride(out, fn),
+                                        cur_stream(out)), fn);
+}
+
 void pair_combine_bwd(const Tensor &g_out, const OptTensor &out, bool relu, const Tensor &src, const Tensor &dst,
                       const Tensor &pair_ptr, const Tensor &node_begin, const Tensor &node_end, Tensor g_ab, Tensor g_c) {
     PSVAE_ON_DEVICE("psvae::pair_combine_bwd", p(g_out), p(out), p(src), p(dst), p(pair_ptr), p(node_begin), p(node_end), p(g_ab), p(g_c));
@@ -538,6 +553,8 @@ TORCH_LIBRARY(psvae, m) {
           &gine_aggregate_bwd_bits);
     m.def("gine_table_reduce(Tensor slabs, Tensor(a!) g_table, bool accumulate) -> ()", &gine_table_reduce);
     m.def("graph_rows_gated(Tensor q, Tensor node_graph, Tensor gate_bits, Tensor(a!) out) -> ()", &graph_rows_gated);
+    m.def("pair_combine_fwd_graphs(Tensor a, Tensor b, Tensor c, Tensor src, Tensor dst, Tensor pair_ptr, Tensor node_begin, "
+          "Tensor node_end, int max_nodes, bool relu, Tensor(a!) out) -> ()", &pair_combine_fwd_graphs);
     m.def("pair_combine_fwd(Tensor a, Tensor b, Tensor c, Tensor src, Tensor dst, Tensor graph, bool relu, Tensor(a!) out) -> ()",
           &pair_combine_fwd);
     m.def("pair_combine_bwd(Tensor g_out, Tensor? out, bool relu, Tensor src, Tensor dst, Tensor pair_ptr, Tensor node_begin, "

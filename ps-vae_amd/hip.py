@@ -81,6 +81,8 @@ _SIGNATURES = {
     'psvae_link_ce_workspace_bytes': (_c_size, [_c_int]),
     'psvae_link_ce_fwd': (_c_int, [_c_int, _c_int, _c_int, _p, _c_int, _p, _p, _p, _p, _p, _p, _p, _p, _p, _c_size, _p]),
     'psvae_link_ce_bwd_input': (_c_int, [_c_int, _c_int, _c_int, _p, _p, _p, _p, _c_int, _p]),
+    'psvae_pair_combine_fwd_graphs': (_c_int, [_c_int, _c_int, _c_int, _p, _c_int, _p, _c_int, _p, _c_int, _p, _p, _p, _p, _p,
+                                               _c_int, _p, _c_int, _p]),
     'psvae_pair_combine_bwd': (_c_int, [_c_int, _c_int, _p, _c_int, _p, _c_int, _c_int, _p, _p, _p, _p, _p, _p, _c_int, _p,
                                         _c_int, _p]),
     'psvae_gemm_f32_bits_words': (_c_size, [_c_int, _c_int]),
@@ -602,6 +604,12 @@ def pair_gather_bwd(g_feats, src, dst, pair_ptr, node_begin, node_end, g_h, g_z)
 def pair_combine_fwd(a, b, c, src, dst, graph, out, relu=True):
     _count()
     ops().pair_combine_fwd(a, b, c, src, dst, graph, relu, out)
+
+
+def pair_combine_fwd_graphs(a, b, c, src, dst, pair_ptr, node_begin, node_end, max_nodes, out, relu=True):
+    """psvae_pair_combine_fwd_graphs: one workgroup per graph, the graph's node rows staged in LDS."""
+    _count()
+    ops().pair_combine_fwd_graphs(a, b, c, src, dst, pair_ptr, node_begin, node_end, int(max_nodes), relu, out)
 
 
 def pair_combine_bwd(g_out, out, relu, src, dst, pair_ptr, node_begin, node_end, g_ab, g_c):

@@ -344,6 +344,7 @@ class VAEPieceDecoder(nn.Module):
         src, dst, graph32, m32, k32, ptr = hip.pair_enumerate(no32, frag.to(dev).to(torch.int32).contiguous(), max_atoms)
         graph, m, k = graph32.to(torch.int64), m32.to(torch.int64), k32.to(torch.int64)
         pairs = ops.PairList(src, dst, graph32, ptr, ops.Segments.from_offsets(no32))
+        pairs.max_nodes = max_atoms
         out = {'graph': graph, 'm': m, 'n': k, 'ptr': ptr}
         P = src.numel()
         if P == 0:

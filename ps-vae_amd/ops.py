@@ -95,6 +95,7 @@ class PairList:
     def __init__(self, src, dst, graph, ptr, nodes):
         self.src, self.dst, self.graph, self.ptr, self.nodes = src, dst, graph, ptr, nodes
         self.live = None   # device int32 [1] when the arrays are fixed-size buffers: only the first live[0] pairs count
+        self.max_nodes = None   # nodes of the largest graph when the builder of the list knows it (sizes an LDS staging area)
 
     def __len__(self):
         return self.src.numel()
@@ -794,7 +795,14 @@ class _PairCombine(Function):
         if ab2.shape[1] != 2 * F:
             raise ValueError(f'pair_combine: node rows of {ab2.shape[1]} columns, graph rows of {F}')
         out = torch.empty(len(pairs), F, dtype=torch.float32, device=ab2.device)
-        hip.pair_combine_fwd(ab2[:, :F], ab2[:, F:], c2, pairs.src, pairs.dst, pairs.graph, out, relu=relu)
+        max_nodes = getattr(pairs, 'max_nodes', None)
+        if max_nodes and len(pairs) >= 4 * ab2.shape[0] and c2.shape[0] >= pairs.ptr.numel() - 1:
+            # many more pairs than nodes (all candidate pairs of generated molecules): a graph's node rows go
+            # through LDS once instead of through the caches once per pair
+            hip.pair_combine_fwd_graphs(ab2[:, :F], ab2[:, F:], c2, pairs.src, pairs.dst, pairs.ptr, pairs.nodes.begin,
+                                        pairs.nodes.end, max_nodes, out, relu=relu)
+        else:
+            hip.pair_combine_fwd(ab2[:, :F], ab2[:, F:], c2, pairs.src, pairs.dst, pairs.graph, out, relu=relu)
         if relu and RELU_TRACE is not None:
             RELU_TRACE.append(out.detach())
         ctx.pairs, ctx.relu, ctx.rows = pairs, relu, ab2.shape[0]

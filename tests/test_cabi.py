@@ -170,7 +170,7 @@ def test_torch_operator_library_registers_its_operators():
              'rsample_kl_bwd', 'token_ce_fwd', 'embed_trans_fwd', 'embed_atom_onehot', 'embedding_fwd', 'onehot',
              'key_sort', 'keyed_row_sum',
              'affine_merge_fwd', 'affine_merge_bwd', 'colsum', 'gru_seq_fwd', 'gru_seq_bwd', 'block_table', 'mse_selected_fwd',
-             'mse_selected_bwd', 'loss_mix_fwd', 'loss_mix_bwd']
+             'mse_selected_bwd', 'loss_mix_fwd', 'loss_mix_bwd', 'pair_combine_fwd_graphs']
     for name in names:
         assert getattr(ops, name)._schema.name == f'psvae::{name}'
     x = torch.zeros(4, 4)

@@ -729,6 +729,35 @@ def test_rsample_kl_fwd_bwd():
     close(pd.grad, pre.grad, what='d/dlogvar')
 
 
+@pytest.mark.parametrize('F,max_nodes', [(328, 40), (328, 12), (64, 40), (1024, 9)])
+def test_pair_combine_per_graph_equals_the_flat_kernel(F, max_nodes):
+    """psvae_pair_combine_fwd_graphs (a graph's node rows staged in LDS) against psvae_pair_combine_fwd on all atom
+    pairs m < k of molecules of 0 .. 30 atoms, bit for bit - also for graphs larger than the staging area
+    (max_nodes 12 and 9), which the kernel serves from memory, and molecules without pairs."""
+    from ps_vae_amd import hip
+    d = dev()
+    rng = np.random.default_rng(F + max_nodes)
+    sizes = [0, 1, 2, 30, 17, 1, 25, 8, 0, 13] + [int(v) for v in rng.integers(2, 31, size=40)]
+    node_off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    src, dst, graph, ptr = [], [], [], [0]
+    for g, n in enumerate(sizes):
+        for m in range(n):
+            for k in range(m + 1, n):
+                src.append(node_off[g] + m), dst.append(node_off[g] + k), graph.append(g)
+        ptr.append(len(src))
+    V, B, P = int(node_off[-1]), len(sizes), len(src)
+    t = lambda a: torch.tensor(np.asarray(a, dtype=np.int32), device=d)   # noqa: E731
+    gen = torch.Generator(device=d).manual_seed(F)
+    ab = torch.randn(V, 2 * F, device=d, generator=gen)
+    c = torch.randn(B, F, device=d, generator=gen)
+    want = torch.empty(P, F, device=d)
+    hip.pair_combine_fwd(ab[:, :F], ab[:, F:], c, t(src), t(dst), t(graph), want, relu=True)
+    got = torch.full((P, F), float('nan'), device=d)
+    hip.pair_combine_fwd_graphs(ab[:, :F], ab[:, F:], c, t(src), t(dst), t(ptr), t(node_off[:-1]), t(node_off[1:]), max_nodes,
+                                got, relu=True)
+    assert torch.equal(got, want)
+
+
 def test_block_table_against_the_slice_assignments():
     """_BlockTable (one launch) against the block matrix written slice by slice, and its gradient views."""
     from ps_vae_amd import ops
