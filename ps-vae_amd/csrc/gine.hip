@@ -113,7 +113,7 @@ __global__ void gine_aggregate_fwd_kernel(int V, int C, int cols, int slots, int
             for (int u = 0; u < 4; ++u)
                 if (e + u < e1) acc = add4(acc, relu_add(xj[u], t[u]));
         }
-        out[(long long)i * ldo4 + c] = add4(acc, self);
+        store_streamed(&out[(long long)i * ldo4 + c], add4(acc, self));
         // (the extra 2-byte store per lane costs the kernel ~15 %: 32-bit words, or collecting a block's words
         // in LDS and writing them as one run, were measured no faster; the backward gains more than this loses)
         if constexpr (!std::is_void<WORD>::value) mask[(long long)i * cols + c] = (WORD)message_bits<MAXC>(self, table, C, cols, c);
@@ -194,7 +194,7 @@ __global__ void gine_aggregate_bwd_kernel(int V, int C, int cols, int slots, int
                         if (kk == k) gt[kk] = add4(gt[kk], m);
                 }
             }
-            g_x[(long long)j * ldgx4 + c] = add4(acc, extra);
+            store_streamed(&g_x[(long long)j * ldgx4 + c], add4(acc, extra));
         }
     }
     if (active) {

@@ -413,11 +413,7 @@ __global__ __launch_bounds__(256) void pair_combine_fwd_graph_kernel(int f4, int
                     const float4 y = staged ? sB[(di[u] - n0) * cp4 + f] : b[(long long)di[u] * ldb4 + f0 + f];
                     float4 o = make_float4((x.x + y.x) + z.x, (x.y + y.y) + z.y, (x.z + y.z) + z.z, (x.w + y.w) + z.w);
                     if (relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
-                    // (streamed: the rows are far more than the caches hold and are read back by a later kernel)
-                    __builtin_nontemporal_store(o.x, &out[(long long)p * ldo4 + f0 + f].x);
-                    __builtin_nontemporal_store(o.y, &out[(long long)p * ldo4 + f0 + f].y);
-                    __builtin_nontemporal_store(o.z, &out[(long long)p * ldo4 + f0 + f].z);
-                    __builtin_nontemporal_store(o.w, &out[(long long)p * ldo4 + f0 + f].w);
+                    store_streamed(&out[(long long)p * ldo4 + f0 + f], o);
                 }
             }
         }
