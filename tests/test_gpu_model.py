@@ -490,6 +490,40 @@ def test_batch_32_train_step_against_oracle(tokenizer, shape):
     batch_32_step_against_oracle(tokenizer, synthetic_step1(32, seed=55, shape=shape))
 
 
+@pytest.mark.parametrize('batch', [32, 512, 4096])
+def test_training_repeats_bit_for_bit(tokenizer, batch):
+    """Two runs of eight training steps from the same seed on the same batches end in the same parameters, bit
+    for bit, with the two-stream fork on: no kernel of the step adds in an order that depends on timing (no
+    atomics: table gradients, pooled sums and split-K slabs are summed in fixed order), and a missing stream
+    dependency between the two branches would show up here as a difference in some run."""
+    from ps_vae_amd.data.bpe_dataset import BPEMolDataset
+    from ps_vae_amd.data.packed import PackedMolecules
+    from ps_vae_amd.data.synthetic import synthetic_step1
+    ds = BPEMolDataset(None, tokenizer, device=dev(), data=PackedMolecules.from_step1(synthetic_step1(2 * batch, seed=77, shape='zinc')))
+    ends = []
+    for run in range(3):
+        model, _ = hip_model(tokenizer, seed=4)
+        model.two_streams_min_nodes = 0
+        (opt,), _ = model.configure_optimizers()
+        opt.max_norm = 10.0
+        model.train()
+        rng = np.random.default_rng(5)
+        torch.manual_seed(6)                      # the noise of the reparameterisation
+        for step in range(8):
+            ids = rng.choice(len(ds), size=batch, replace=False)
+            uniforms = torch.rand(600 * batch, dtype=torch.float64, device=dev(), generator=torch.Generator(device=dev()).manual_seed(step))
+            opt.zero_grad()
+            loss = model.training_step(ds.collate_ids(ids, reference_layout=False, uniforms=uniforms), step)
+            loss.backward()
+            opt.step()
+            model.global_step += 1
+        torch.cuda.synchronize()
+        ends.append({k: v.detach().clone() for k, v in model.state_dict().items()})
+    for other in ends[1:]:
+        bad = [k for k in ends[0] if not torch.equal(ends[0][k], other[k])]
+        assert not bad, f'parameters differ between two identical runs: {bad[:5]}'
+
+
 @pytest.mark.parametrize('name', ['qm9', 'zinc'])
 def test_batch_32_train_step_on_real_molecules(name):
     """The same step on REAL molecules: the first 32 SMILES of the reference's data/qm9/train.txt and
