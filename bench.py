@@ -74,7 +74,9 @@ def make_dataset(num, seed, tok, device, shape='zinc'):
             data = [mol_bpe.process_step1(line.strip(), tok) for line in f if line.strip()]
         packed = PackedMolecules.from_step1(data)
         try:
-            packed.save(cache)
+            tmp = f'{cache}.{os.getpid()}.tmp.npz'
+            packed.save(tmp)
+            os.replace(tmp, cache)
         except OSError:
             pass
         return BPEMolDataset(None, tok, device=device, data=packed)
@@ -84,7 +86,9 @@ def make_dataset(num, seed, tok, device, shape='zinc'):
     else:
         packed = PackedMolecules.from_step1(synthetic_step1(num, seed=seed, shape=shape))
         try:
-            packed.save(cache)
+            tmp = f'{cache}.{os.getpid()}.tmp.npz'      # (another process may be looking for the same cache file)
+            packed.save(tmp)
+            os.replace(tmp, cache)
         except OSError:
             pass
     return BPEMolDataset(None, tok, device=device, data=packed)
