@@ -1023,12 +1023,15 @@ def test_pair_combine_fwd_bwd(B, N, F, dense):
     close(cd.grad, c.grad, what='d / d c')
 
 
+@pytest.mark.parametrize('F,C', [(656, 4), (328, 4), (64, 3), (512, 7), (330, 4), (100, 8)])
 @pytest.mark.parametrize('P', [0, 1, 5, 4097])
-def test_link_ce_fwd_bwd(P):
+def test_link_ce_fwd_bwd(P, F, C):
+    """The class layer + cross-entropy kernels in every form: half a wave per pair (rows up to 512 floats, two to four
+    float4 per lane, up to 4 or 8 classes), one wave per pair (wider rows), scalar loads (a width that is no
+    multiple of 4); the input gradient as float4 columns and as scalars."""
     from ps_vae_amd import ops
     d = dev()
-    g = torch.Generator().manual_seed(13 + P)
-    F, C = 656, 4
+    g = torch.Generator().manual_seed(13 + P + F)
     hid = torch.randn(P, F, generator=g, requires_grad=True)
     w = (torch.randn(C, F, generator=g) * 0.05).requires_grad_()
     b = torch.randn(C, generator=g, requires_grad=True)
