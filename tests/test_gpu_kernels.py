@@ -993,7 +993,7 @@ def test_pair_gather_bwd_many_pairs_per_graph():
     close(zd.grad, z.grad, what='d pair / dz')
 
 
-@pytest.mark.parametrize('B,N,F,dense', [(5, 13, 328, 0.1), (2, 60, 36, 0.6), (3, 7, 8, 0.0)])
+@pytest.mark.parametrize('B,N,F,dense', [(5, 13, 328, 0.1), (2, 60, 36, 0.6), (3, 7, 8, 0.0), (2, 9, 2048, 0.5)])
 def test_pair_combine_fwd_bwd(B, N, F, dense):
     """relu(ab[src][:F] + ab[dst][F:] + c[graph]) per pair and its backward (gated sums into the node
     and graph rows, in pair order) against autograd in float64: a training-sized case, one with more
